@@ -1,0 +1,1078 @@
+/*
+ * ttx_oracle.c -- CPU restatement (TEST ORACLE) of the reference's dtt_dmrgg greedy-cross sweep.
+ * See ttx_oracle.h for status and rules of use.  Plain C99, single thread, fp64, no BLAS.
+ * Must be compiled with -ffp-contract=off so that every a*b+c is two IEEE roundings, like the
+ * reference's -O2 x86-64 build (no FMA in the baseline ISA).
+ *
+ * Index conventions follow the Fortran source (1-based cores p=1..m, bonds p=1..m-1 joining cores p,p+1)
+ * so that each block can be read next to the cited reference lines.
+ */
+#include "ttx_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * BLAS restated in netlib reference order (the reference links -lblas; lib/dmrgg.f90:55-56)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* idamax: first index (1-based) of max |x|; strict '>' keeps the lowest index on ties */
+static int o_idamax(int n, const double *x, int incx)
+{
+    if (n < 1) return 0;
+    int imax = 1;
+    double dmax = fabs(x[0]);
+    for (int i = 2; i <= n; i++) {
+        double v = fabs(x[(size_t)(i - 1) * incx]);
+        if (v > dmax) { imax = i; dmax = v; }
+    }
+    return imax;
+}
+
+static double o_ddot(int n, const double *x, int incx, const double *y, int incy)
+{
+    double t = 0.0;
+    for (int i = 0; i < n; i++) t = t + x[(size_t)i * incx] * y[(size_t)i * incy];
+    return t;
+}
+
+/* y := alpha*A*x + beta*y, A m x n column-major, beta in {0,1}; netlib axpy form */
+static void o_dgemv_n(int m, int n, double alpha, const double *a, int lda, const double *x, int incx,
+                      double beta, double *y, int incy)
+{
+    if (beta == 0.0) for (int i = 0; i < m; i++) y[(size_t)i * incy] = 0.0;
+    for (int j = 0; j < n; j++) {
+        double temp = alpha * x[(size_t)j * incx];
+        for (int i = 0; i < m; i++) y[(size_t)i * incy] = y[(size_t)i * incy] + temp * a[i + (size_t)lda * j];
+    }
+}
+
+/* y := alpha*A'*x + beta*y, A m x n column-major; netlib dot form */
+static void o_dgemv_t(int m, int n, double alpha, const double *a, int lda, const double *x, int incx,
+                      double beta, double *y, int incy)
+{
+    if (beta == 0.0) for (int j = 0; j < n; j++) y[(size_t)j * incy] = 0.0;
+    for (int j = 0; j < n; j++) {
+        double temp = 0.0;
+        for (int i = 0; i < m; i++) temp = temp + a[i + (size_t)lda * j] * x[(size_t)i * incx];
+        y[(size_t)j * incy] = y[(size_t)j * incy] + alpha * temp;
+    }
+}
+
+/* C := A*B (alpha=1, beta=0), netlib 'n','n' order */
+static void o_dgemm_nn(int m, int n, int k, const double *a, int lda, const double *b, int ldb, double *c, int ldc)
+{
+    for (int j = 0; j < n; j++) {
+        for (int i = 0; i < m; i++) c[i + (size_t)ldc * j] = 0.0;
+        for (int l = 0; l < k; l++) {
+            double temp = b[l + (size_t)ldb * j];
+            for (int i = 0; i < m; i++) c[i + (size_t)ldc * j] = c[i + (size_t)ldc * j] + temp * a[i + (size_t)lda * l];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * lib/lr.f90:124-154  d2_lual / d2_luar  (packed LU 'g')
+ * ---------------------------------------------------------------------------------------------- */
+void ttxo_lual(int m, int r, const double *g, double *col, int from)
+{
+    /* lr.f90:133-138: col(:,p) -= col(:,1:p-1)*g(p^2-p+1 : p^2-1); col(:,p) *= 1/g(p^2) */
+    for (int p = from; p <= r; p++) {
+        if (p > 1) o_dgemv_n(m, p - 1, -1.0, col, m, g + (p * p - p + 1 - 1), 1, 1.0, col + (size_t)m * (p - 1), 1);
+        double s = 1.0 / g[p * p - 1];
+        for (int i = 0; i < m; i++) col[i + (size_t)m * (p - 1)] = s * col[i + (size_t)m * (p - 1)];
+    }
+}
+
+void ttxo_luar(int n, int r, const double *g, double *row, int from)
+{
+    /* lr.f90:149-153: row(p,:) -= g(p^2-2p+2 : p^2-p)' * row(1:p-1,:) */
+    for (int p = from; p <= r; p++) {
+        if (p > 1) o_dgemv_t(p - 1, n, -1.0, row, r, g + (p * p - 2 * p + 2 - 1), 1, 1.0, row + (p - 1), r);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * RNG: the reference calls the compiler's random_number (lib/rnd.f90:120), never seeded.  The golden
+ * logs were produced with amdflang (LLVM flang runtime): minstd (48271 mod 2^31-1) from seed 1, two
+ * words per double: f = (w1<<30 | ((w2-1)&(2^30-1))) >> 7, value = f * 2^-54.  Verified draw-for-draw
+ * against amdflang's random_number in this container (tests/golden/flang_rng.txt).
+ * ---------------------------------------------------------------------------------------------- */
+#define MINSTD_M 2147483647ULL
+static uint64_t mulmod(uint64_t a, uint64_t b) { return (a * b) % MINSTD_M; }
+static uint64_t powmod(uint64_t a, uint64_t e)
+{
+    uint64_t r = 1;
+    while (e) { if (e & 1) r = mulmod(r, a); a = mulmod(a, a); e >>= 1; }
+    return r;
+}
+double ttxo_flang_draw(uint64_t k)
+{
+    uint64_t w1 = powmod(48271ULL, 2 * k + 1); /* seed 1 */
+    uint64_t w2 = mulmod(w1, 48271ULL);
+    uint64_t f = (w1 << 30) | ((w2 - 1) & ((1ULL << 30) - 1));
+    f >>= 7;
+    return ldexp((double)f, -54);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * lib/rnd.f90:105-144  lottery2 + find_d
+ * ---------------------------------------------------------------------------------------------- */
+static int o_find_d(int n, const double *x /* x[1..n] as x[0..n-1] */, double y)
+{
+    /* rnd.f90:128-143: pos with x(pos) <= y < x(pos+1) */
+    if (n == 0) return 0;
+    if (y < x[0]) return 0;
+    if (x[n - 1] <= y) return n;
+    int s = 1, t = n, pos = (t + s) / 2;
+    while (t - s > 1) {
+        if (y < x[pos - 1]) t = pos; else s = pos;
+        pos = (s + t) / 2;
+    }
+    return pos;
+}
+
+void ttxo_lottery2(int npnt, int m, int n, const double *wcol, const double *wrow, const double *d, int32_t *points)
+{
+    /* rnd.f90:116-124; d(npnt,2) column-major uniform draws */
+    double *pcol = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    double *prow = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    double scol = 0.0, srow = 0.0;
+    for (int i = 0; i < m; i++) scol = scol + fabs(wcol[i]);
+    for (int j = 0; j < n; j++) srow = srow + fabs(wrow[j]);
+    pcol[0] = 0.0; for (int i = 1; i <= m; i++) pcol[i] = pcol[i - 1] + fabs(wcol[i - 1]) / scol;
+    prow[0] = 0.0; for (int j = 1; j <= n; j++) prow[j] = prow[j - 1] + fabs(wrow[j - 1]) / srow;
+    for (int ip = 0; ip < npnt; ip++) {
+        int a = o_find_d(m + 1, pcol, d[ip]);        if (a > m) a = m;
+        int b = o_find_d(n + 1, prow, d[npnt + ip]); if (b > n) b = n;
+        points[ip] = a; points[npnt + ip] = b;
+    }
+    free(pcol); free(prow);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * lib/quad.f90:97-131  lgwt
+ * ---------------------------------------------------------------------------------------------- */
+void ttxo_lgwt(int n, double *x, double *w)
+{
+    const double tpi = 6.2831853071795864769252867665590057683943387987502116419498891846156328125724179972560696506842341359642961730265646132941876892191011644634507188162569622349005682054038770422111192892458979098607639288576219513318668922569512964675735663305424038182912971338469206972209086532964267872145204982825474491740132126311763497630418419256585081834307287357851807200226610610976409330427682939038830232188661145407315191839061843722347638652235862102370961489247599254991347037715054497824558763660238982596673467248813132861720427898927904494743814043597218874055410784343525863535047693496369353388102640011362542905271216555715426855155792183472743574429368818024499068602930991707421015845593785178470840399122242580439217280688363196272595495426199210374144226999999967459560999021194634656321926371900489189106938166052850446165066893700705238623763420200062756775057731750664167628412343553382946071965069808575109374623191257277647075751875039155637155610643424536132260038557532223918184328403;
+    double small = 5 * 2.220446049250313e-16;
+    int m = (n + 1) / 2;
+    for (int i = 1; i <= m; i++) {
+        double z = cos((tpi * (4 * i - 1)) / (8 * n + 4));
+        double z1, p1, p2, p3, pp;
+        do {
+            p1 = 1.0; p2 = 0.0;
+            for (int j = 1; j <= n; j++) {
+                p3 = p2; p2 = p1;
+                p1 = ((2 * j - 1) * z * p2 - (j - 1) * p3) / j;
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1);
+            z1 = z;
+            z = z1 - p1 / pp;
+        } while (fabs(z - z1) > small);
+        x[i - 1] = -z; x[n - i] = z;
+        w[i - 1] = 2.0 / ((1 - z * z) * pp * pp);
+        w[n - i] = w[i - 1];
+    }
+}
+
+/* lib/default.f90:78-97 */
+void ttxo_share(int first, int last, int nproc, int32_t *own)
+{
+    own[0] = first;
+    for (int p = 1; p < nproc; p++) own[p] = first + (int)((double)(last - first + 1) * (double)p / nproc);
+    own[nproc] = last + 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * integrands (user callbacks of the reference drivers); ind is 1-based, par as the reference's par(*)
+ * ---------------------------------------------------------------------------------------------- */
+static double powi(double a, int b)
+{
+    /* integer power by squaring, as the compiler run-time lowers x**n */
+    double r = 1.0;
+    for (;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; }
+    return r;
+}
+
+double ttxo_fun(int fun_id, int m, const int32_t *ind, const int32_t *n, const double *par, const double *aux)
+{
+    if (fun_id == TTXO_FUN_ISING) {
+        /* test_crs_ising.f90:176-218 */
+        const int n1 = n[0];
+        const int id = (int)par[2 * n1];
+        const double *nodes = par - 1;        /* par(nodes+ind) with ind 1-based */
+        const double *weights = par + n1 - 1;
+        double a = 1.0, b = 0.0, f;
+        if (id == 2 || id == 3) {
+            for (int i = 0; i <= m; i++) {
+                double uij = 1.0;
+                for (int j = i + 1; j <= m; j++) {
+                    uij = uij * nodes[ind[j - 1]];
+                    double t = (uij - 1.0) / (uij + 1.0);
+                    a = a * (t * t);
+                }
+            }
+        }
+        if (id == 1 || id == 2) {
+            double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
+            for (int i = 1; i <= m; i++) {
+                vk = vk * nodes[ind[m - i]];
+                wk = wk * nodes[ind[i - 1]];
+                v = v + vk;
+                w = w + wk;
+            }
+            b = 1.0 / (v * w);
+        }
+        if (id == 1) f = 2 * b; else if (id == 2) f = 2 * a * b; else f = 2 * a;
+        for (int i = 0; i < m; i++) f = f * weights[ind[i]];
+        return f;
+    }
+    if (fun_id == TTXO_FUN_STDNORM) {
+        /* test_crs_stdnorm.f90:154-170 */
+        double s = 0.0;
+        for (int i = 0; i < m; i++) { double x = par[ind[i] - 1]; s = s + x * x; }
+        return exp(-s);
+    }
+    if (fun_id == TTXO_FUN_MVN) {
+        /* test_crs_mvn.f90:156-172 + lib/mvn_pdf.f90:63-83; aux = mu[m], inv_cov[m*m], det */
+        const double pi = 3.141592653589793;
+        const double *mu = aux, *ic = aux + m;
+        double det = aux[m + (size_t)m * m];
+        double ex = 0.0;
+        for (int i = 0; i < m; i++) {
+            double di = par[ind[i] - 1] - mu[i];
+            for (int j = 0; j < m; j++) {
+                double dj = par[ind[j] - 1] - mu[j];
+                ex = ex + di * ic[i + (size_t)m * j] * dj;
+            }
+        }
+        return exp(-0.5 * ex) / sqrt(powi(2.0 * pi, m) * det);
+    }
+    fprintf(stderr, "ttx_oracle: unknown fun_id %d\n", fun_id);
+    exit(2);
+}
+
+/* lib/mvn_pdf.f90:21-60 (mean/covariance) and :85-111 (LU inverse + determinant; LAPACK dgetrf/dgetri
+ * restated as unblocked partial-pivot LU followed by column-by-column solves) */
+void ttxo_mvn_init(int n, double r, double T, double *aux)
+{
+    const double sigma = 0.4, corr = 0.5;
+    double X0 = log(100.0);
+    double *mu = aux, *inv = aux + n;
+    double *a = (double *)malloc(sizeof(double) * (size_t)n * n);
+    int *ipiv = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; i++) mu[i] = X0 + (r - 0.5 * (sigma * sigma)) * T;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) a[i + (size_t)n * j] = ((i == j) ? sigma * sigma : sigma * corr * sigma) * T;
+    double det = 1.0;
+    for (int k = 0; k < n; k++) {
+        int piv = k; double mx = fabs(a[k + (size_t)n * k]);
+        for (int i = k + 1; i < n; i++) if (fabs(a[i + (size_t)n * k]) > mx) { mx = fabs(a[i + (size_t)n * k]); piv = i; }
+        ipiv[k] = piv;
+        if (piv != k) for (int j = 0; j < n; j++) { double t = a[k + (size_t)n * j]; a[k + (size_t)n * j] = a[piv + (size_t)n * j]; a[piv + (size_t)n * j] = t; }
+        double rp = 1.0 / a[k + (size_t)n * k];
+        for (int i = k + 1; i < n; i++) a[i + (size_t)n * k] *= rp;
+        for (int j = k + 1; j < n; j++) {
+            double t = a[k + (size_t)n * j];
+            for (int i = k + 1; i < n; i++) a[i + (size_t)n * j] -= a[i + (size_t)n * k] * t;
+        }
+    }
+    for (int i = 0; i < n; i++) { if (ipiv[i] != i) det = -det; det = det * a[i + (size_t)n * i]; }
+    /* inverse: solve A X = I column by column with the LU factors */
+    for (int c = 0; c < n; c++) {
+        double *x = inv + (size_t)n * c;
+        for (int i = 0; i < n; i++) x[i] = (i == c) ? 1.0 : 0.0;
+        for (int k = 0; k < n; k++) if (ipiv[k] != k) { double t = x[k]; x[k] = x[ipiv[k]]; x[ipiv[k]] = t; }
+        for (int k = 0; k < n; k++) for (int i = k + 1; i < n; i++) x[i] -= a[i + (size_t)n * k] * x[k];
+        for (int k = n - 1; k >= 0; k--) { x[k] /= a[k + (size_t)n * k]; for (int i = 0; i < k; i++) x[i] -= a[i + (size_t)n * k] * x[k]; }
+    }
+    aux[n + (size_t)n * n] = det;
+    free(a); free(ipiv);
+}
+
+/* driver parameter set-up; returns the number of TT cores d */
+int ttxo_driver_setup(char kind, int m, int n, double *par, double *quadw, double *tru, double *acc, int *rescale)
+{
+    const double eps = 2.220446049250313e-16;
+    int d;
+    *tru = 0.0; *rescale = 0;
+    ttxo_lgwt(n, par, par + n);
+    if (kind == 'c' || kind == 'd' || kind == 'e' || kind == 'C' || kind == 'D' || kind == 'E') {
+        /* test_crs_ising.f90:60-69,102-144 (the analytic table :71-100 is kept by the caller/tests) */
+        char k = (char)(kind | 0x20);
+        d = m - 1;
+        *acc = 500 * eps;
+        par[2 * n] = (k == 'c') ? 1.0 : (k == 'd') ? 2.0 : 3.0;
+        for (int i = 0; i < n; i++) par[n + i] = 0.5 * par[n + i];
+        for (int i = 0; i < n; i++) par[i] = (par[i] + 1.0) / 2;
+        *rescale = (k == 'd' || k == 'e') && (m >= 10);
+        double val = (double)(n / 2);
+        double sc = *rescale ? 5.0 * val : val;
+        for (int i = 0; i < n; i++) par[n + i] = sc * par[n + i];
+        for (int i = 0; i < d * n; i++) quadw[i] = 1.0 / val;
+        return d;
+    }
+    double a, b;
+    d = m;
+    if (kind == 's') {          /* test_crs_stdnorm.f90:70-112 */
+        *acc = 5 * eps; a = -10.0; b = 10.0;
+        *tru = powi(sqrt(3.141592653589793238), d);
+    } else {                    /* test_crs_mvn.f90:72-118 */
+        *acc = 500 * eps; a = (double)0.525170f; b = (double)8.525170f; *tru = 1.0;
+    }
+    for (int i = 0; i < n; i++) par[i] = 0.5 * ((b - a) * par[i] + (a + b));
+    for (int i = 0; i < n; i++) par[n + i] = (0.5 * (b - a)) * par[n + i];
+    par[2 * n] = 0.0;
+    for (int k = 0; k < d; k++) for (int i = 0; i < n; i++) quadw[k * n + i] = par[n + i];
+    return d;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * TT cores: column-major (r0, n, r1), lib/tt.f90:18-37
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int r0, n, r1; double *p; } core_t;
+#define C3(c, i, j, k) ((c).p[((i) - 1) + (size_t)(c).r0 * (((j) - 1) + (size_t)(c).n * ((k) - 1))])
+
+static void core_alloc(core_t *c, int r0, int n, int r1)
+{
+    free(c->p);
+    c->r0 = r0; c->n = n; c->r1 = r1;
+    c->p = (double *)calloc((size_t)r0 * n * r1 + 1, sizeof(double));
+}
+static void core_copy(core_t *dst, const core_t *src)
+{
+    core_alloc(dst, src->r0, src->n, src->r1);
+    memcpy(dst->p, src->p, sizeof(double) * (size_t)src->r0 * src->n * src->r1);
+}
+/* grow the third dimension by one slab (contents of the new slab are left to the caller) */
+static void core_grow3(core_t *c)
+{
+    c->p = (double *)realloc(c->p, sizeof(double) * ((size_t)c->r0 * c->n * (c->r1 + 1) + 1));
+    c->r1 += 1;
+}
+/* grow the first dimension by one row (new entries zero until written) */
+static void core_grow1(core_t *c)
+{
+    int r0 = c->r0, nr = c->n * c->r1;
+    double *q = (double *)calloc((size_t)(r0 + 1) * nr + 1, sizeof(double));
+    for (int x = 0; x < nr; x++) memcpy(q + (size_t)(r0 + 1) * x, c->p + (size_t)r0 * x, sizeof(double) * r0);
+    free(c->p); c->p = q; c->r0 = r0 + 1;
+}
+
+typedef struct {
+    int me;
+    int *r, *rr;
+    core_t *arg, *col, *row;
+    double **inv;
+    int **vip;
+    int *tape, *tmpp;
+    unsigned char *upd;
+    double amax, pivotmax, pivotmin, pivotmax_prev;
+    int64_t nevalloc;
+    uint64_t rngpos;
+} rank_t;
+
+typedef struct {
+    const ttxo_problem *pb;
+    int m;              /* cores 1..m */
+    const int32_t *n;   /* n[p-1] */
+    int nproc;
+    int32_t *own;       /* own[0..nproc] */
+    rank_t *rk;
+} ctx_t;
+#define NN(p) (cx->n[(p) - 1])
+
+/* lib/dmrgg.f90:1053-1078 */
+static double dmrgg_fun(const ctx_t *cx, const rank_t *k_, int i, int j, int k, int q, int p)
+{
+    int32_t ind[2050];
+    const int m = cx->m;
+    int t = i;
+    for (int s = p - 1; s >= 1; s--) { ind[s - 1] = k_->vip[s][4 * (t - 1) + 1]; t = k_->vip[s][4 * (t - 1) + 0]; }
+    ind[p - 1] = j;
+    ind[p] = k;
+    t = q;
+    for (int s = p + 1; s <= m - 1; s++) { ind[s] = k_->vip[s][4 * (t - 1) + 2]; t = k_->vip[s][4 * (t - 1) + 3]; }
+    return ttxo_fun(cx->pb->fun_id, m, ind, cx->n, cx->pb->par, cx->pb->aux);
+}
+
+static double next_draw(const ctx_t *cx, rank_t *k)
+{
+    double v;
+    if (cx->pb->draws) {
+        if ((int64_t)k->rngpos >= cx->pb->ndraws) { fprintf(stderr, "ttx_oracle: draw tape exhausted\n"); exit(2); }
+        v = cx->pb->draws[k->rngpos];
+    } else v = ttxo_flang_draw(k->rngpos);
+    k->rngpos++;
+    return v;
+}
+
+/* lib/tt.f90:1228-1245 */
+static double erank(const ctx_t *cx, const int *r)
+{
+    int l = 1, m = cx->m, d = m - l + 1;
+    if (d <= 0) return -1.0;
+    if (d == 1) return 0.0;
+    double s = 0.0;
+    for (int i = l; i <= m; i++) s = s + r[i - 1] * NN(i) * r[i];
+    if (s == 0.0) return s;
+    int b = r[l - 1] * NN(l) + NN(m) * r[m];
+    if (d == 2) return s / b;
+    int a = 0;
+    for (int i = l + 1; i <= m - 1; i++) a += NN(i);
+    return (sqrt(b * b + 4.0 * a * s) - b) / (2.0 * a);
+}
+
+/* Fortran Ew.d edit descriptor for non-negative values (0.dddE+ee, leading zero dropped if w is tight) */
+static void fmt_e(char *out, int w, int dgt, double v)
+{
+    char tmp[64], body[64];
+    int ex = 0;
+    if (v != 0.0 && isfinite(v)) {
+        snprintf(tmp, sizeof tmp, "%.*e", dgt - 1, v);
+        char *e = strchr(tmp, 'e');
+        ex = atoi(e + 1) + 1;
+        *e = 0;
+        char digs[40]; int nd = 0;
+        for (char *c = tmp; *c; c++) if (*c >= '0' && *c <= '9') digs[nd++] = *c;
+        digs[nd] = 0;
+        snprintf(body, sizeof body, ".%sE%c%02d", digs, ex < 0 ? '-' : '+', abs(ex));
+    } else {
+        char z[40]; memset(z, '0', (size_t)dgt); z[dgt] = 0;
+        snprintf(body, sizeof body, ".%sE+00", z);
+    }
+    int len = (int)strlen(body);
+    if (len + 1 <= w) { snprintf(tmp, sizeof tmp, "0%s", body); snprintf(out, 64, "%*s", w, tmp); }
+    else snprintf(out, 64, "%*s", w, body);
+}
+
+/* lib/dmrgg.f90:1169-1258 dtt_lua applied to an array of cores (arg or ttqq) of every rank.
+ * The rightmost inv of each rank is first shifted to its right neighbour (:1209-1246). */
+static void dtt_lua_all(ctx_t *cx, core_t **tt /* tt[me][p] */, int nmode_is_one)
+{
+    (void)nmode_is_one;
+    const int P = cx->nproc;
+    if (P > 1) {
+        for (int me = P - 1; me >= 1; me--) {       /* receive from me-1; process right-to-left so senders are unmodified */
+            rank_t *k = &cx->rk[me], *s = &cx->rk[me - 1];
+            int p = cx->own[me] - 1;                /* == s's last bond q */
+            int rp = k->r[p];
+            free(k->inv[p]);
+            k->inv[p] = (double *)malloc(sizeof(double) * (size_t)rp * rp);
+            memcpy(k->inv[p], s->inv[p], sizeof(double) * (size_t)rp * rp);
+        }
+    }
+    for (int me = 0; me < P; me++) {
+        rank_t *k = &cx->rk[me];
+        for (int p = cx->own[me]; p <= cx->own[me + 1] - 1; p++) {
+            core_t *u = &tt[me][p];
+            ttxo_luar(u->n * k->r[p], k->r[p - 1], k->inv[p - 1], u->p, 1);
+            ttxo_lual(k->r[p - 1] * u->n, k->r[p], k->inv[p], u->p, 1);
+        }
+        if (me == P - 1) {
+            int m = cx->own[me + 1];
+            core_t *u = &tt[me][m];
+            ttxo_luar(u->n * k->r[m], k->r[m - 1], k->inv[m - 1], u->p, 1);
+        }
+    }
+}
+
+/* lib/dmrgg.f90:1261-1415 dtt_quad over all ranks; quadw NULL -> sum over modes (:1330-1332) */
+static double dtt_quad_all(ctx_t *cx, core_t **tt, const double *quadw, const int32_t *own)
+{
+    const int P = cx->nproc;
+    double **prev = (double **)calloc((size_t)P, sizeof(double *));
+    int *mym = (int *)calloc((size_t)P, sizeof(int)), *myn = (int *)calloc((size_t)P, sizeof(int));
+    for (int me = 0; me < P; me++) {
+        rank_t *k = &cx->rk[me];
+        int first = own[me], last = own[me + 1] - 1;
+        if (me == P - 1) last = cx->m;
+        double *pv = NULL;
+        for (int p = first; p <= last; p++) {
+            core_t *u = &tt[me][p];
+            int r0 = k->r[p - 1], r1 = k->r[p];
+            double *curr = (double *)calloc((size_t)r0 * r1 + 1, sizeof(double));
+            if (quadw) {
+                const double *w = quadw;
+                for (int c = 1; c < p; c++) w += NN(c);
+                for (int kk = 1; kk <= r1; kk++)
+                    o_dgemv_n(r0, u->n, 1.0, &C3(*u, 1, 1, kk), r0, w, 1, 0.0, curr + (size_t)r0 * (kk - 1), 1);
+            } else {
+                for (int kk = 1; kk <= r1; kk++) for (int i = 1; i <= r0; i++) {
+                    double s = 0.0;
+                    for (int j = 1; j <= u->n; j++) s = s + C3(*u, i, j, kk);
+                    curr[(i - 1) + (size_t)r0 * (kk - 1)] = s;
+                }
+            }
+            if (p == first) pv = curr;
+            else {
+                int rf = k->r[first - 1];
+                double *next = (double *)calloc((size_t)rf * r1 + 1, sizeof(double));
+                o_dgemm_nn(rf, r1, r0, pv, rf, curr, r0, next, rf);
+                free(pv); free(curr); pv = next;
+            }
+        }
+        prev[me] = pv; mym[me] = k->r[first - 1]; myn[me] = k->r[last];
+    }
+    /* binary tree :1355-1405 */
+    for (int q = 1; q < P; q *= 2) {
+        for (int me = 0; me < P; me++) {
+            if (me % (2 * q) == 0) {
+                int her = me + q;
+                if (her < P) {
+                    if (myn[me] != mym[her]) { fprintf(stderr, "ttx_oracle: dtt_quad size mismatch\n"); exit(2); }
+                    double *next = (double *)calloc((size_t)mym[me] * myn[her] + 1, sizeof(double));
+                    o_dgemm_nn(mym[me], myn[her], myn[me], prev[me], mym[me], prev[her], mym[her], next, mym[me]);
+                    free(prev[me]); prev[me] = next; myn[me] = myn[her];
+                }
+            }
+        }
+    }
+    double val = prev[0][0];
+    for (int me = 0; me < P; me++) free(prev[me]);
+    free(prev); free(mym); free(myn);
+    return val;
+}
+
+static void append_vip(rank_t *k, int p, const int *t4)
+{
+    int rp = k->r[p];
+    k->vip[p] = (int *)realloc(k->vip[p], sizeof(int) * 4 * (size_t)(rp + 1));
+    memcpy(k->vip[p] + 4 * rp, t4, sizeof(int) * 4);
+}
+
+/* one bond step of the main loop, lib/dmrgg.f90:329-760 */
+static void bond_step(ctx_t *cx, rank_t *k, int p, int dir)
+{
+    const int me = k->me, piv = cx->pb->piv;
+    const double small_element = 10 * 2.220446049250313e-16, small_pivot = 1.e-5;  /* :70-71 */
+    int *r = k->r;
+    const int r0 = r[p - 1], r1 = r[p], r2 = r[p + 1], n1 = NN(p), n2 = NN(p + 1);
+    core_t *colp = &k->col[p], *rowq = &k->row[p + 1];
+    double *acol1 = (double *)calloc((size_t)r0 * n1 + 1, sizeof(double));
+    double *arow1 = (double *)calloc((size_t)n2 * r2 + 1, sizeof(double));
+    int ii = 0, jj = 0, kk = 0, qq = 0;
+    double pivot = 0.0;
+
+    if (piv == -1) {
+        /* :341-408 full pivoting over the superblock */
+        size_t tot = (size_t)r0 * n1 * n2 * r2;
+        double *a = (double *)malloc(sizeof(double) * tot), *b = (double *)malloc(sizeof(double) * tot);
+        for (size_t x = 0; x < tot; x++) {
+            size_t i = x;
+            int q = (int)(i / ((size_t)r0 * n1 * n2)); i %= (size_t)r0 * n1 * n2;
+            int kx = (int)(i / ((size_t)r0 * n1)); i %= (size_t)r0 * n1;
+            int j = (int)(i / r0); int i1 = (int)(i % r0);
+            a[x] = dmrgg_fun(cx, k, i1 + 1, j + 1, kx + 1, q + 1, p);
+        }
+        k->nevalloc += (int64_t)tot;
+        int x = o_idamax((int)tot, a, 1) - 1;
+        k->amax = fmax(k->amax, fabs(a[x]));
+        memcpy(b, a, sizeof(double) * tot);
+        /* b -= col(p) * row(p+1): dgemm 'n','n' alpha=-1 beta=1 (:384), netlib order */
+        for (int c = 0; c < n2 * r2; c++)
+            for (int l = 0; l < r1; l++) {
+                double temp = -1.0 * rowq->p[l + (size_t)r1 * c];
+                for (int i = 0; i < r0 * n1; i++) b[i + (size_t)r0 * n1 * c] = b[i + (size_t)r0 * n1 * c] + temp * colp->p[i + (size_t)r0 * n1 * l];
+            }
+        x = o_idamax((int)tot, b, 1) - 1;
+        pivot = b[x];
+        qq = x / (r0 * n1 * n2) + 1; x %= (r0 * n1 * n2);
+        kk = x / (r0 * n1) + 1; x %= (r0 * n1);
+        jj = x / r0 + 1; ii = x % r0 + 1;
+        for (int j = 1; j <= n1; j++) for (int i = 1; i <= r0; i++)
+            acol1[(i - 1) + r0 * (j - 1)] = a[(i - 1) + (size_t)r0 * ((j - 1) + (size_t)n1 * ((kk - 1) + (size_t)n2 * (qq - 1)))];
+        for (int q = 1; q <= r2; q++) for (int kx = 1; kx <= n2; kx++)
+            arow1[(kx - 1) + n2 * (q - 1)] = a[(ii - 1) + (size_t)r0 * ((jj - 1) + (size_t)n1 * ((kx - 1) + (size_t)n2 * (q - 1)))];
+        free(a); free(b);
+    } else {
+        /* :410-484 lottery */
+        const int nlot = r0 + n1 + n2 + r2;
+        double *bcol1 = (double *)malloc(sizeof(double) * ((size_t)r0 * n1 + 1));
+        double *brow1 = (double *)malloc(sizeof(double) * ((size_t)n2 * r2 + 1));
+        int32_t *pts = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)nlot);
+        int *lot = (int *)malloc(sizeof(int) * 4 * (size_t)nlot);
+        double *b = (double *)malloc(sizeof(double) * (size_t)nlot);
+        double *dr = (double *)malloc(sizeof(double) * 2 * (size_t)nlot);
+        for (int x = 0; x < r0 * n1; x++) bcol1[x] = 1.0;
+        for (int x = 0; x < n2 * r2; x++) brow1[x] = 1.0;
+        for (int s = 1; s <= r1; s++) {
+            const int *v = k->vip[p] + 4 * (s - 1);
+            bcol1[(v[0] - 1) + r0 * (v[1] - 1)] = 0.0;
+            brow1[(v[2] - 1) + n2 * (v[3] - 1)] = 0.0;
+        }
+        for (int x = 0; x < 2 * nlot; x++) dr[x] = next_draw(cx, k);
+        ttxo_lottery2(nlot, r0 * n1, n2 * r2, bcol1, brow1, dr, pts);
+        for (int il = 0; il < nlot; il++) {                                   /* :443-452 */
+            int a = pts[il], c = pts[nlot + il];
+            lot[4 * il + 1] = (a - 1) / r0 + 1; lot[4 * il + 0] = (a - 1) % r0 + 1;
+            lot[4 * il + 3] = (c - 1) / n2 + 1; lot[4 * il + 2] = (c - 1) % n2 + 1;
+        }
+        for (int il = 0; il < nlot; il++)                                     /* :455-463 */
+            b[il] = dmrgg_fun(cx, k, lot[4 * il], lot[4 * il + 1], lot[4 * il + 2], lot[4 * il + 3], p);
+        k->nevalloc += nlot;
+        int il = o_idamax(nlot, b, 1);
+        k->amax = fmax(k->amax, fabs(b[il - 1]));
+        for (il = 0; il < nlot; il++) {                                       /* :469-476 */
+            int i = lot[4 * il], j = lot[4 * il + 1], kx = lot[4 * il + 2], q = lot[4 * il + 3];
+            b[il] = b[il] - o_ddot(r1, &C3(*colp, i, j, 1), r0 * n1, &C3(*rowq, 1, kx, q), 1);
+        }
+        il = o_idamax(nlot, b, 1);
+        ii = lot[4 * (il - 1)]; jj = lot[4 * (il - 1) + 1]; kk = lot[4 * (il - 1) + 2]; qq = lot[4 * (il - 1) + 3];
+        pivot = b[il - 1];
+
+        int done = 0, havecol = 0, haverow = 0;
+        if (piv == 0) {                                                       /* :492-513 */
+            for (int ij = 0; ij < r0 * n1; ij++) acol1[ij] = dmrgg_fun(cx, k, ij % r0 + 1, ij / r0 + 1, kk, qq, p);
+            for (int kq = 0; kq < n2 * r2; kq++) arow1[kq] = dmrgg_fun(cx, k, ii, jj, kq % n2 + 1, kq / n2 + 1, p);
+            k->nevalloc += r0 * n1 + n2 * r2;
+            done = havecol = haverow = 1;
+        }
+        int crs = 0, skipcol = (dir == 2);                                    /* :516-582 rook */
+        while (!done) {
+            if (!skipcol) {
+                for (int ij = 0; ij < r0 * n1; ij++) acol1[ij] = dmrgg_fun(cx, k, ij % r0 + 1, ij / r0 + 1, kk, qq, p);
+                k->nevalloc += r0 * n1;
+                int ij = o_idamax(r0 * n1, acol1, 1) - 1;
+                k->amax = fmax(k->amax, fabs(acol1[ij]));
+                havecol = 1; crs++;
+                done = havecol && haverow && (crs >= 2 * piv);
+                if (!done) {
+                    memcpy(bcol1, acol1, sizeof(double) * (size_t)r0 * n1);
+                    o_dgemv_n(r0 * n1, r1, -1.0, colp->p, r0 * n1, &C3(*rowq, 1, kk, qq), 1, 1.0, bcol1, 1);
+                    ij = o_idamax(r0 * n1, bcol1, 1) - 1;
+                    int j = ij / r0 + 1, i = ij % r0 + 1;
+                    done = havecol && haverow && (i == ii && j == jj);
+                    ii = i; jj = j;
+                    pivot = bcol1[(ii - 1) + r0 * (jj - 1)];
+                }
+            }
+            skipcol = 0;
+            if (!done) {
+                for (int kq = 0; kq < n2 * r2; kq++) arow1[kq] = dmrgg_fun(cx, k, ii, jj, kq % n2 + 1, kq / n2 + 1, p);
+                k->nevalloc += n2 * r2;
+                int kq = o_idamax(n2 * r2, arow1, 1) - 1;
+                k->amax = fmax(k->amax, fabs(arow1[kq]));
+                haverow = 1; crs++;
+                done = havecol && haverow && (crs >= 2 * piv);
+                if (!done) {
+                    memcpy(brow1, arow1, sizeof(double) * (size_t)n2 * r2);
+                    o_dgemv_t(r1, n2 * r2, -1.0, rowq->p, r1, &C3(*colp, ii, jj, 1), r0 * n1, 1.0, brow1, 1);
+                    kq = o_idamax(n2 * r2, brow1, 1) - 1;
+                    int q = kq / n2 + 1, kx = kq % n2 + 1;
+                    done = havecol && haverow && (kx == kk && q == qq);
+                    qq = q; kk = kx;
+                    pivot = brow1[(kk - 1) + n2 * (qq - 1)];
+                }
+            }
+        }
+        free(bcol1); free(brow1); free(pts); free(lot); free(b); free(dr);
+    }
+
+    /* :598-600 acceptance */
+    for (int x = 0; x < 4; x++) k->tape[4 * p + x] = -1;
+    k->upd[p] = (fabs(pivot) > small_element * k->amax) && (fabs(pivot) > small_pivot * k->pivotmax_prev);
+    if (k->upd[p]) {
+        int t4[4] = { ii, jj, kk, qq };
+        memcpy(k->tape + 4 * p, t4, sizeof t4);
+        append_vip(k, p, t4);                                                 /* :604-623 */
+        k->pivotmax = (k->pivotmax < 0.0) ? fabs(pivot) : fmax(k->pivotmax, fabs(pivot));
+        k->pivotmin = (k->pivotmin < 0.0) ? fabs(pivot) : fmin(k->pivotmin, fabs(pivot));
+        /* :649-660 grow packed LU with values of the OLD factors */
+        double *g = (double *)realloc(k->inv[p], sizeof(double) * (size_t)(r1 + 1) * (r1 + 1));
+        for (int s = 1; s <= r1; s++) g[r1 * r1 + (s - 1)] = C3(*colp, ii, jj, s);
+        for (int s = 1; s <= r1; s++) g[r1 * r1 + r1 + (s - 1)] = C3(*rowq, s, kk, qq);
+        g[(r1 + 1) * (r1 + 1) - 1] = pivot;
+        k->inv[p] = g;
+        /* :662-685 raw fibers into arg */
+        core_grow3(&k->arg[p]);
+        memcpy(&C3(k->arg[p], 1, 1, r1 + 1), acol1, sizeof(double) * (size_t)r0 * n1);
+        core_grow1(&k->arg[p + 1]);
+        for (int q = 1; q <= r2; q++) for (int kx = 1; kx <= n2; kx++) C3(k->arg[p + 1], r1 + 1, kx, q) = arow1[(kx - 1) + n2 * (q - 1)];
+        /* :687-713 LU-scaled factors */
+        core_grow3(colp);
+        memcpy(&C3(*colp, 1, 1, r1 + 1), acol1, sizeof(double) * (size_t)r0 * n1);
+        core_grow1(rowq);
+        for (int q = 1; q <= r2; q++) for (int kx = 1; kx <= n2; kx++) C3(*rowq, r1 + 1, kx, q) = arow1[(kx - 1) + n2 * (q - 1)];
+        ttxo_lual(r0 * n1, r1 + 1, g, colp->p, r1 + 1);
+        ttxo_luar(n2 * r2, r1 + 1, g, rowq->p, r1 + 1);
+        if (p > cx->own[me]) {                                                /* :715-728 left rows */
+            core_t *rp = &k->row[p];
+            core_grow3(rp);
+            double *bc = &C3(*rp, 1, 1, r1 + 1);
+            memcpy(bc, acol1, sizeof(double) * (size_t)r0 * n1);
+            ttxo_luar(n1, r0, k->inv[p - 1], bc, 1);
+        }
+        if (p < cx->own[me + 1] - 1) {                                        /* :730-749 right cols */
+            core_t *cq = &k->col[p + 1];
+            double *br = (double *)malloc(sizeof(double) * ((size_t)n2 * r2 + 1));
+            memcpy(br, arow1, sizeof(double) * (size_t)n2 * r2);
+            ttxo_lual(n2, r2, k->inv[p + 1], br, 1);
+            core_grow1(cq);
+            for (int q = 1; q <= r2; q++) for (int kx = 1; kx <= n2; kx++) C3(*cq, r1 + 1, kx, q) = br[(kx - 1) + n2 * (q - 1)];
+            free(br);
+        }
+        r[p] = r1 + 1;                                                        /* :752 */
+    }
+    free(acol1); free(arow1);
+}
+
+int ttxo_dmrgg(const ttxo_problem *pb, ttxo_result *res)
+{
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    ctx_t cxs, *cx = &cxs;
+    memset(cx, 0, sizeof *cx);
+    memset(res, 0, sizeof *res);
+    const int m = pb->d, P = pb->nproc < 1 ? 1 : pb->nproc;
+    cx->pb = pb; cx->m = m; cx->n = pb->n; cx->nproc = P;
+    if (P >= m) { fprintf(stderr, "nproc exceeds or equal dimension, cannot proceed\n"); return 1; } /* :114-117 */
+    if (m > 2040) { fprintf(stderr, "ttx_oracle: d exceeds tt_size\n"); return 1; }
+    cx->own = (int32_t *)calloc((size_t)P + 1, sizeof(int32_t));
+    if (pb->mybonds) memcpy(cx->own, pb->mybonds, sizeof(int32_t) * ((size_t)P + 1));
+    else ttxo_share(1, m - 1, P, cx->own);                                    /* :126-130 */
+    cx->rk = (rank_t *)calloc((size_t)P, sizeof(rank_t));
+    const int has_quad = pb->quadw != NULL;
+    const int cap = (pb->maxrank > 0 ? pb->maxrank : 4096) + 2;
+    res->d = m;
+    res->sweeps = (ttxo_sweep_rec *)calloc((size_t)cap, sizeof(ttxo_sweep_rec));
+    res->tapes = (int32_t *)calloc((size_t)cap * (m + 1) * 4, sizeof(int32_t));
+
+    for (int me = 0; me < P; me++) {
+        rank_t *k = &cx->rk[me];
+        k->me = me;
+        k->r = (int *)calloc((size_t)m + 2, sizeof(int)); k->rr = (int *)calloc((size_t)m + 2, sizeof(int));
+        k->arg = (core_t *)calloc((size_t)m + 2, sizeof(core_t));
+        k->col = (core_t *)calloc((size_t)m + 2, sizeof(core_t));
+        k->row = (core_t *)calloc((size_t)m + 2, sizeof(core_t));
+        k->inv = (double **)calloc((size_t)m + 2, sizeof(double *));
+        k->vip = (int **)calloc((size_t)m + 2, sizeof(int *));
+        k->tape = (int *)calloc(4 * ((size_t)m + 2), sizeof(int)); k->tmpp = (int *)calloc(4 * ((size_t)m + 2), sizeof(int));
+        k->upd = (unsigned char *)calloc((size_t)m + 2, 1);
+        for (int p = 0; p <= m; p++) {                                        /* :96-100, :141-148 */
+            k->r[p] = 1;
+            k->inv[p] = (double *)malloc(sizeof(double)); k->inv[p][0] = 1.0;
+            k->vip[p] = (int *)calloc(4, sizeof(int));
+        }
+        for (int p = 1; p <= m; p++) core_alloc(&k->arg[p], 1, NN(p), 1);
+    }
+
+    /* ---- locating the initial cross :151-217 ---- */
+    const int smin = 8;
+    const int snum = smin > P ? smin : P;
+    int *shifts = (int *)calloc((size_t)P + 1, sizeof(int));
+    for (int p = 0; p < P; p++) shifts[p] = (int)((double)snum * (double)p / P);
+    shifts[P] = snum;
+    int nn = NN(1);
+    for (int p = 2; p <= m; p++) if (NN(p) < nn) nn = NN(p);
+    double gmax = 0.0; int gilot = 0;
+    int32_t ind[2050];
+    memset(ind, 0, sizeof ind);
+    for (int me = 0; me < P; me++) {
+        rank_t *k = &cx->rk[me];
+        int ihave = shifts[me + 1] - shifts[me], nlot = nn * ihave;
+        double *b = (double *)malloc(sizeof(double) * ((size_t)nlot + 1));
+        for (int s = 0; s < ihave; s++)
+            for (int kx = 1; kx <= nn; kx++) {
+                for (int p = 1; p <= m; p++) ind[p - 1] = (kx - 1 + (s + shifts[me]) * (p - 1)) % NN(p) + 1;
+                b[(kx - 1) + s * nn] = ttxo_fun(pb->fun_id, m, ind, cx->n, pb->par, pb->aux);
+            }
+        int ilot = o_idamax(nlot, b, 1);
+        k->amax = fabs(b[ilot - 1]);
+        k->nevalloc = nlot;
+        ilot += nn * shifts[me];
+        free(b);
+        /* MPI_MAXLOC :196 -- max value, lowest location on ties */
+        if (me == 0 || k->amax > gmax || (k->amax == gmax && ilot < gilot)) { gmax = k->amax; gilot = ilot; }
+    }
+    {
+        int s = (gilot - 1) / nn, kx = (gilot - 1) % nn + 1;
+        for (int p = 1; p <= m; p++) ind[p - 1] = (kx - 1 + s * (p - 1)) % NN(p) + 1;
+    }
+    for (int me = 0; me < P; me++) {
+        rank_t *k = &cx->rk[me];
+        if (P > 1) k->amax = gmax;
+        int one[4] = { 1, 1, 1, 1 };
+        memcpy(k->vip[0], one, sizeof one); memcpy(k->vip[m], one, sizeof one);
+        for (int p = 1; p <= m - 1; p++) { int v[4] = { 1, ind[p - 1], ind[p], 1 }; memcpy(k->vip[p], v, sizeof v); }
+        /* :221-232 initial fibers for own cores own(me)..own(me+1) */
+        for (int p = cx->own[me]; p <= cx->own[me + 1]; p++) {
+            for (int j = 1; j <= NN(p); j++) C3(k->arg[p], 1, j, 1) = dmrgg_fun(cx, k, 1, j, ind[p], 1, p);
+            k->nevalloc += NN(p);
+            for (int j = 1; j <= NN(p); j++) k->amax = fmax(k->amax, fabs(C3(k->arg[p], 1, j, 1)));
+        }
+        k->pivotmax_prev = k->amax;                                           /* :234 */
+        for (int p = cx->own[me]; p <= cx->own[me + 1] - 1; p++) k->inv[p][0] = C3(k->arg[p], 1, ind[p - 1], 1);
+        for (int p = 1; p <= m; p++) { core_copy(&k->col[p], &k->arg[p]); core_copy(&k->row[p], &k->arg[p]); } /* :243-244 */
+        for (int p = cx->own[me]; p <= cx->own[me + 1] - 1; p++) {
+            ttxo_lual(NN(p), 1, k->inv[p], k->col[p].p, 1);
+            ttxo_luar(NN(p + 1), 1, k->inv[p], k->row[p + 1].p, 1);
+        }
+    }
+    /* note: ind(p+1) in :224 for p == m reads ind(m+1): the reference passes k=ind(p+1) which for the
+     * last core is past the end; dmrgg_fun then writes ind(p+1)=k beyond m, which fun ignores. */
+    double val = 0.0, val_prev = 0.0;
+    if (has_quad) {                                                           /* :250-270 */
+        double prod = 1.0;
+        for (int me = 0; me < P; me++) {
+            rank_t *k = &cx->rk[me];
+            double v = 1.0;
+            const double *w = pb->quadw;
+            for (int c = 1; c < cx->own[me]; c++) w += NN(c);
+            for (int p = cx->own[me]; p <= cx->own[me + 1] - 1; p++) { v = v * o_ddot(NN(p), k->arg[p].p, 1, w, 1) / k->inv[p][0]; w += NN(p); }
+            if (me == P - 1) v = v * o_ddot(NN(m), k->arg[m].p, 1, w, 1);
+            prod = (me == 0) ? v : prod * v;
+        }
+        val = prod; val_prev = val;
+    }
+    int64_t nevalall = 0;
+    for (int me = 0; me < P; me++) nevalall += cx->rk[me].nevalloc;
+    for (int me = 0; me < P; me++) {
+        rank_t *k = &cx->rk[me];
+        for (int p = 0; p <= m; p++) { for (int x = 0; x < 4; x++) { k->tape[4 * p + x] = -1; k->tmpp[4 * p + x] = -2; } k->upd[p] = 0; }
+    }
+    int nrec = 0;
+    {
+        ttxo_sweep_rec *sr = &res->sweeps[nrec++];
+        sr->it = 0; sr->dir = 0; sr->erank = erank(cx, cx->rk[0].r); sr->neval = nevalall; sr->val = val;
+        sr->amax = cx->rk[0].amax; sr->pivotmax = -1; sr->pivotmin = -1;
+        if (pb->verbose) {
+            char e1[64], e2[64];
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
+            fmt_e(e1, 9, 3, (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec));
+            printf("%3d%2s%s%5.1f%s%s%s%10lld", 0, "::", " rank", sr->erank, " time: ", e1, " n_evals: ", (long long)nevalall);
+            if (has_quad) { fmt_e(e2, 20, 14, val); printf(" val %s", e2); }
+            printf("\n");
+        }
+    }
+
+    /* ---- main loop :309-1020 ---- */
+    int it = 0, strike = 0, ready = 0;
+    if (pb->maxrank > 0) ready = (it + 1 >= pb->maxrank);
+    core_t **ttqq = (core_t **)calloc((size_t)P, sizeof(core_t *));
+    core_t **targ = (core_t **)calloc((size_t)P, sizeof(core_t *));
+    for (int me = 0; me < P; me++) { ttqq[me] = (core_t *)calloc((size_t)m + 2, sizeof(core_t)); targ[me] = cx->rk[me].arg; }
+
+    while (!ready) {
+        it++;
+        int dir = 2 - it % 2;
+        for (int me = 0; me < P; me++) {
+            rank_t *k = &cx->rk[me];
+            memcpy(k->rr, k->r, sizeof(int) * ((size_t)m + 1));
+            k->pivotmax = -1.0; k->pivotmin = -1.0;
+            int nb = cx->own[me + 1] - cx->own[me];
+            for (int pp = 1; pp <= nb; pp++) {
+                int p = cx->own[me] + pp - 1;
+                if (dir == 2) p = cx->own[me + 1] - pp;
+                bond_step(cx, k, p, dir);
+            }
+        }
+        /* record owner tapes */
+        {
+            int32_t *tp = res->tapes + (size_t)(it - 1) * (m + 1) * 4;
+            for (int me = 0; me < P; me++)
+                for (int p = cx->own[me]; p <= cx->own[me + 1] - 1; p++) memcpy(tp + 4 * p, cx->rk[me].tape + 4 * p, sizeof(int32_t) * 4);
+        }
+        if (P > 1) {
+            /* :763-820 tapes right then left (all sends read `tape`, all receives write `tmpp`) */
+            for (int me = 0; me < P; me++) { rank_t *k = &cx->rk[me]; for (int x = 0; x < 4 * (m + 1); x++) k->tmpp[x] = -2; }
+            for (int me = 1; me < P; me++) {
+                rank_t *k = &cx->rk[me], *s = &cx->rk[me - 1];
+                int ineed = cx->own[me] - 1;          /* bonds 1..own(me)-1 */
+                memcpy(k->tmpp + 4 * 1, s->tape + 4 * 1, sizeof(int) * 4 * (size_t)ineed);
+            }
+            for (int me = 0; me < P - 1; me++) {
+                rank_t *k = &cx->rk[me], *s = &cx->rk[me + 1];
+                int pq = cx->own[me + 1], ineed = m - cx->own[me + 1];
+                memcpy(k->tmpp + 4 * pq, s->tape + 4 * pq, sizeof(int) * 4 * (size_t)ineed);
+            }
+            /* :822-850 apply foreign tape */
+            for (int me = 0; me < P; me++) {
+                rank_t *k = &cx->rk[me];
+                memcpy(k->tape, k->tmpp, sizeof(int) * 4 * ((size_t)m + 1));
+                for (int p = 1; p <= m - 1; p++) {
+                    if (!(cx->own[me] <= p && p <= cx->own[me + 1] - 1)) {
+                        k->upd[p] = (k->tape[4 * p] > 0);
+                        if (k->upd[p]) { append_vip(k, p, k->tape + 4 * p); k->r[p] += 1; }
+                    }
+                }
+            }
+            /* :852-870 allreduce MAX */
+            double a = -1e300, b = -1e300, c = -1e300;
+            for (int me = 0; me < P; me++) {
+                rank_t *k = &cx->rk[me];
+                a = fmax(a, k->amax); b = fmax(b, k->pivotmax);
+                c = fmax(c, (k->pivotmin > 0.0) ? -k->pivotmin : -999e9);
+            }
+            for (int me = 0; me < P; me++) {
+                rank_t *k = &cx->rk[me];
+                k->amax = a; k->pivotmax = b; k->pivotmin = -c;
+                if (k->pivotmin == 999e9) k->pivotmin = -1.0;
+            }
+            /* :872-958 share blocks to the LEFT: messages first, then receives */
+            double **msg = (double **)calloc((size_t)P, sizeof(double *));
+            for (int me = 1; me < P; me++) {
+                rank_t *k = &cx->rk[me];
+                int q = cx->own[me];
+                if (k->upd[q]) {
+                    int cnt = k->rr[q - 1] * NN(q);
+                    msg[me] = (double *)malloc(sizeof(double) * ((size_t)cnt + 1));
+                    memcpy(msg[me], &C3(k->arg[q], 1, 1, k->r[q]), sizeof(double) * (size_t)cnt);
+                }
+            }
+            for (int me = 0; me < P - 1; me++) {
+                rank_t *k = &cx->rk[me];
+                int p = cx->own[me + 1] - 1;
+                if (!k->upd[p + 1]) continue;
+                const double *arow1 = msg[me + 1];              /* (rr(p), n(p+1)) */
+                core_t *u = &k->arg[p + 1];
+                core_grow3(u);
+                int rp = k->r[p], rrp = k->rr[p], n2 = NN(p + 1), rq = k->r[p + 1];
+                for (int kx = 1; kx <= n2; kx++) for (int j = 1; j <= rp; j++) C3(*u, j, kx, rq) = 0.0;
+                for (int kx = 1; kx <= n2; kx++) for (int j = 1; j <= rrp; j++) C3(*u, j, kx, rq) = arow1[(j - 1) + rrp * (kx - 1)];
+                if (k->upd[p]) {
+                    int ii = k->vip[p][4 * (rp - 1)], jj = k->vip[p][4 * (rp - 1) + 1];
+                    for (int kx = 1; kx <= n2; kx++) C3(*u, rp, kx, rq) = dmrgg_fun(cx, k, ii, jj, kx, rq, p);
+                    for (int kx = 1; kx <= n2; kx++) k->amax = fmax(k->amax, fabs(C3(*u, rp, kx, rq)));
+                    k->nevalloc += n2;
+                }
+                core_t *rw = &k->row[p + 1];
+                core_grow3(rw);
+                memcpy(&C3(*rw, 1, 1, rq), &C3(*u, 1, 1, rq), sizeof(double) * (size_t)rp * n2);
+                ttxo_luar(n2, rp, k->inv[p], &C3(*rw, 1, 1, rq), 1);
+            }
+            for (int me = 0; me < P; me++) { free(msg[me]); msg[me] = NULL; }
+            /* share blocks to the RIGHT (lost in the fp64 source; lib/dmrggmp.f90:572-629) */
+            for (int me = 0; me < P - 1; me++) {
+                rank_t *k = &cx->rk[me];
+                int q = cx->own[me + 1] - 1;
+                if (k->upd[q]) {
+                    int n2 = NN(q + 1), rrq1 = k->rr[q + 1], rq = k->r[q];
+                    msg[me] = (double *)malloc(sizeof(double) * ((size_t)n2 * rrq1 + 1));
+                    for (int c = 1; c <= rrq1; c++) for (int kx = 1; kx <= n2; kx++) msg[me][(kx - 1) + n2 * (c - 1)] = C3(k->arg[q + 1], rq, kx, c);
+                }
+            }
+            for (int me = 1; me < P; me++) {
+                rank_t *k = &cx->rk[me];
+                int p = cx->own[me];
+                if (!k->upd[p - 1]) continue;
+                const double *acol1 = msg[me - 1];              /* (n(p), rr(p)) */
+                int n1 = NN(p), rrp = k->rr[p], rp = k->r[p], r0 = k->r[p - 1];
+                core_t *u = &k->arg[p];
+                core_grow1(u);                                  /* first dim rr(p-1) -> r(p-1) */
+                for (int c = 1; c <= rrp; c++) for (int j = 1; j <= n1; j++) C3(*u, r0, j, c) = acol1[(j - 1) + n1 * (c - 1)];
+                if (k->upd[p]) {
+                    int kk = k->vip[p][4 * (rp - 1) + 2], qq = k->vip[p][4 * (rp - 1) + 3];
+                    for (int j = 1; j <= n1; j++) C3(*u, r0, j, rp) = dmrgg_fun(cx, k, r0, j, kk, qq, p);
+                    for (int j = 1; j <= n1; j++) k->amax = fmax(k->amax, fabs(C3(*u, r0, j, rp)));
+                    k->nevalloc += n1;
+                }
+                double *bcol1 = (double *)malloc(sizeof(double) * ((size_t)n1 * rp + 1));
+                for (int c = 1; c <= rp; c++) for (int j = 1; j <= n1; j++) bcol1[(j - 1) + n1 * (c - 1)] = C3(*u, r0, j, c);
+                ttxo_lual(n1, rp, k->inv[p], bcol1, 1);
+                core_t *cl = &k->col[p];
+                core_grow1(cl);
+                for (int c = 1; c <= rp; c++) for (int j = 1; j <= n1; j++) C3(*cl, r0, j, c) = bcol1[(j - 1) + n1 * (c - 1)];
+                free(bcol1);
+            }
+            for (int me = 0; me < P; me++) free(msg[me]);
+            free(msg);
+        }
+        for (int me = 0; me < P; me++) cx->rk[me].pivotmax_prev = cx->rk[me].pivotmax;   /* :961 */
+        nevalall = 0;
+        for (int me = 0; me < P; me++) nevalall += cx->rk[me].nevalloc;
+
+        ttxo_sweep_rec *sr = &res->sweeps[nrec++];
+        sr->it = it; sr->dir = dir; sr->erank = erank(cx, cx->rk[0].r); sr->neval = nevalall;
+        sr->amax = cx->rk[0].amax; sr->pivotmax = cx->rk[0].pivotmax; sr->pivotmin = cx->rk[0].pivotmin;
+        if (has_quad) {                                                       /* :975-1006 */
+            for (int me = 0; me < P; me++) {
+                rank_t *k = &cx->rk[me];
+                int first = cx->own[me], last = cx->own[me + 1] - 1;
+                if (me == P - 1) last = m;
+                const double *w = pb->quadw;
+                for (int c = 1; c < first; c++) w += NN(c);
+                for (int p = first; p <= last; p++) {
+                    core_t *t = &ttqq[me][p];
+                    core_alloc(t, k->r[p - 1], 1, k->r[p]);
+                    for (int kk = 1; kk <= k->r[p]; kk++)
+                        o_dgemv_n(k->r[p - 1], NN(p), 1.0, &C3(k->arg[p], 1, 1, kk), k->r[p - 1], w, 1, 0.0, &C3(*t, 1, 1, kk), 1);
+                    w += NN(p);
+                }
+            }
+            dtt_lua_all(cx, ttqq, 1);
+            val = dtt_quad_all(cx, ttqq, NULL, cx->own);
+            sr->val = val;
+        }
+        if (pb->verbose) {
+            char e1[64], e2[64], e3[64];
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
+            fmt_e(e1, 9, 3, (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec));
+            printf("%3d%2s%s%5.1f%s%s%s%10lld", it, dir == 1 ? ">>" : "<<", " rank", sr->erank, " time: ", e1, " n_evals: ", (long long)nevalall);
+            if (has_quad) {
+                fmt_e(e3, 20, 14, val);
+                if (pb->has_tru) { fmt_e(e2, 8, 3, fabs(1.0 - val / pb->tru)); printf(" err %s val %s", e2, e3); }
+                else { fmt_e(e2, 8, 3, fabs(1.0 - val / val_prev)); printf(" cnv %s val %s", e2, e3); }
+            }
+            printf("\n");
+        }
+        val_prev = val;
+        /* :1010-1019 exit conditions (rank 0's view; identical on all ranks after the allreduce) */
+        if (pb->maxrank > 0) ready = ready || (it + 1 >= pb->maxrank);
+        if (pb->accuracy >= 0.0) {
+            if (cx->rk[0].pivotmax <= pb->accuracy * cx->rk[0].amax) strike++; else strike = 0;
+            ready = ready || (strike >= 3);
+        }
+        if (nrec >= cap) ready = 1;
+    }
+    res->nsweeps = nrec;
+
+    /* :1029 finalise */
+    dtt_lua_all(cx, targ, 0);
+    res->neval = nevalall;
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    res->seconds = (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
+
+    /* driver's dtt_quad(tt, qq) (test_crs_ising.f90:158) with the default share() partition */
+    if (has_quad) res->value = dtt_quad_all(cx, targ, pb->quadw, cx->own);
+
+    /* export: ranks as rank P-1 .. rank 0 agree on own ranges; take each core from its owner */
+    res->r = (int32_t *)calloc((size_t)m + 1, sizeof(int32_t));
+    res->cores = (double **)calloc((size_t)m, sizeof(double *));
+    for (int me = 0; me < P; me++) {
+        rank_t *k = &cx->rk[me];
+        int first = cx->own[me], last = cx->own[me + 1] - 1;
+        if (me == P - 1) last = m;
+        for (int p = first; p <= last; p++) {
+            res->r[p - 1] = k->r[p - 1]; res->r[p] = k->r[p];
+            size_t sz = (size_t)k->arg[p].r0 * k->arg[p].n * k->arg[p].r1;
+            res->cores[p - 1] = (double *)malloc(sizeof(double) * (sz + 1));
+            memcpy(res->cores[p - 1], k->arg[p].p, sizeof(double) * sz);
+        }
+    }
+    /* free */
+    for (int me = 0; me < P; me++) {
+        rank_t *k = &cx->rk[me];
+        for (int p = 0; p <= m + 1; p++) {
+            if (p <= m) { free(k->inv[p]); free(k->vip[p]); }
+            free(k->arg[p].p); free(k->col[p].p); free(k->row[p].p); free(ttqq[me][p].p);
+        }
+        free(k->r); free(k->rr); free(k->arg); free(k->col); free(k->row); free(k->inv); free(k->vip);
+        free(k->tape); free(k->tmpp); free(k->upd); free(ttqq[me]);
+    }
+    free(ttqq); free(targ); free(cx->rk); free(cx->own); free(shifts);
+    return 0;
+}
+
+void ttxo_free_result(ttxo_result *res)
+{
+    if (!res) return;
+    free(res->sweeps); free(res->tapes); free(res->r);
+    if (res->cores) { for (int k = 0; k < res->d; k++) free(res->cores[k]); free(res->cores); }
+    memset(res, 0, sizeof *res);
+}

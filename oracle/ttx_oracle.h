@@ -1,0 +1,104 @@
+/*
+ * ttx_oracle.h -- CPU restatement (test oracle) of the reference's dtt_dmrgg greedy-cross sweep.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; the product (libttx.so, the HIP engine) never links,
+ * loads or calls anything in oracle/.
+ *
+ * Parity status: PINNED -- checked against golden logs produced by the genuine reference built in this
+ * container from /root/reference (oracle/Makefile target `ref`, outputs in oracle/_ref/, fixtures in
+ * tests/golden/ made by tests/golden/make_golden.sh) and against the analytic Ising values embedded in
+ * the reference driver (test_crs_ising.f90:71-100).
+ *
+ * Every function cites the reference file:line it restates.  BLAS is an external dependency of the
+ * reference (any conforming implementation; the golden logs were made with MKL 'sequential'); its
+ * level-1/2/3 routines are restated here in the summation order of the published netlib reference BLAS
+ * (idamax, ddot, dgemv 'n'/'t', dgemm 'nn', dscal, dasum).
+ */
+#ifndef TTX_ORACLE_H
+#define TTX_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* integrand ids shared with include/ttx.h */
+enum {
+    TTXO_FUN_ISING = 1,   /* dfunc_ising_discr, test_crs_ising.f90:176-218; par(2n+1) selects C/D/E   */
+    TTXO_FUN_STDNORM = 2, /* integrand, test_crs_stdnorm.f90:154-170                                   */
+    TTXO_FUN_MVN = 3      /* integrand -> mvn_pdf, test_crs_mvn.f90:156-172, lib/mvn_pdf.f90:63-83     */
+};
+
+typedef struct ttxo_sweep_rec {
+    int32_t it;        /* sweep number, 0 = initial cross                     */
+    int32_t dir;       /* 0 '::', 1 '>>', 2 '<<'                              */
+    double erank;      /* erank(arg) as seen by rank 0, lib/tt.f90:1228-1245  */
+    int64_t neval;     /* summed over ranks, lib/dmrgg.f90:273,963            */
+    double val;        /* per-sweep quadrature value (0 when no quad)         */
+    double amax;       /* after the per-sweep MAX allreduce                   */
+    double pivotmax;   /* idem (-1 when nothing was accepted)                 */
+    double pivotmin;
+} ttxo_sweep_rec;
+
+typedef struct ttxo_problem {
+    int32_t d;               /* number of cores (reference: l=1, m=d)                                */
+    const int32_t *n;        /* mode sizes n[0..d-1]                                                 */
+    int32_t fun_id;          /* TTXO_FUN_*                                                           */
+    const double *par;       /* integrand parameters (nodes, weights, id), as the reference's par(*) */
+    int32_t npar;
+    const double *aux;       /* MVN: mu[d], inv_cov[d*d] column-major, det; else NULL                */
+    int32_t naux;
+    const double *quadw;     /* rank-1 quadrature TT: d blocks of n[k] weights, or NULL              */
+    double accuracy;         /* <0: absent                                                           */
+    int32_t maxrank;         /* <=0: absent                                                          */
+    int32_t piv;             /* -1 full, 0 lottery only, >0 rook half-steps (default 3)              */
+    double tru;              /* analytic value                                                       */
+    int32_t has_tru;
+    int32_t nproc;           /* virtual MPI ranks (>=1, < d)                                         */
+    const int32_t *mybonds;  /* own(0:nproc) 1-based bonds, or NULL -> share()                       */
+    int32_t verbose;         /* 1: print the reference's per-sweep lines to stdout                   */
+    const double *draws;     /* optional replay tape of uniform draws (NULL -> flang-compatible LCG)  */
+    int64_t ndraws;
+} ttxo_problem;
+
+typedef struct ttxo_result {
+    int32_t d;
+    int32_t nsweeps;           /* number of records (initial cross included)                        */
+    ttxo_sweep_rec *sweeps;    /* [nsweeps]                                                          */
+    int32_t *tapes;            /* [nsweeps-1][d+1][4] owner tapes per sweep (bond p at [p], 1-based) */
+    int32_t *r;                /* final ranks r[0..d] (rank 0's view == global after last exchange) */
+    double **cores;            /* finalised cores k=0..d-1, column-major r[k] x n[k] x r[k+1]        */
+    int64_t neval;
+    double value;              /* dtt_quad(tt, qq) after finalisation (0 when no quad)               */
+    double seconds;            /* wall time of the dmrgg call                                        */
+} ttxo_result;
+
+/* lib/dmrgg.f90:11-1050 (+ lib/dmrggmp.f90:572-629 for the right-going boundary exchange). */
+int ttxo_dmrgg(const ttxo_problem *prob, ttxo_result *res);
+void ttxo_free_result(ttxo_result *res);
+
+/* lib/quad.f90:97-131 */
+void ttxo_lgwt(int n, double *x, double *w);
+/* lib/default.f90:78-97 */
+void ttxo_share(int first, int last, int nproc, int32_t *own);
+/* lib/mvn_pdf.f90:21-60,85-111 : mu, inv_cov (column-major d*d), det for the driver's r=0,T=1 */
+void ttxo_mvn_init(int d, double r, double T, double *aux /* d + d*d + 1 */);
+/* integrand evaluation (1-based ind), test_crs_*.f90 */
+double ttxo_fun(int fun_id, int m, const int32_t *ind, const int32_t *n, const double *par, const double *aux);
+/* flang runtime random_number stream (unseeded): draw #k (0-based) */
+double ttxo_flang_draw(uint64_t k);
+/* lib/lr.f90:124-154 */
+void ttxo_lual(int m, int r, const double *g, double *col, int from);
+void ttxo_luar(int n, int r, const double *g, double *row, int from);
+/* lib/rnd.f90:105-144 */
+void ttxo_lottery2(int npnt, int m, int n, const double *wcol, const double *wrow, const double *d, int32_t *points);
+/* driver parameter set-up: test_crs_ising.f90:102-144, test_crs_mvn.f90:76-118, test_crs_stdnorm.f90:72-112.
+ * kind: 'c','d','e' (ising; m = integral index, d = m-1), 's' stdnorm, 'm' mvn (m = dimension).
+ * par must hold 2n+1 doubles, quadw d*n doubles; returns d and *tru (0 when the driver has none). */
+int ttxo_driver_setup(char kind, int m, int n, double *par, double *quadw, double *tru, double *acc, int *rescale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Regenerates the golden logs in this directory from the GENUINE reference built by `make -C oracle ref`
+# (oracle/_ref/, from /root/reference; amdflang + MPICH + MKL sequential).  Only program OUTPUT is stored:
+# the per-sweep lines of lib/dmrgg.f90:971-1008 and the footer of the drivers, with the noisy `time:`
+# column blanked.  File name = driver arguments (+ _npP for P MPI ranks of the patched build).
+set -e
+cd "$(dirname "$0")/../.."
+export MKL_THREADING_LAYER=SEQUENTIAL OMP_NUM_THREADS=1
+R=oracle/_ref
+G=tests/golden
+norm() { grep -E 'n_evals|computed value|analytic value|correct digits|\.\.\.with' | sed -E 's/time: [0-9.E+-]+/time: -/; s/completed in +[0-9.E+-]+ sec\./completed/'; }
+run1() { local drv=$1; shift; local tag=$(echo "$drv $*" | tr ' ' '_'); $R/test_crs_$drv "$@" | norm > $G/$tag.txt; echo $tag; }
+runp() { local np=$1; shift; local tag=$(echo "ising $*" | tr ' ' '_')_np$np; /opt/conda/bin/mpiexec -np $np $R/test_crs_ising_mpi "$@" | norm > $G/$tag.txt; echo $tag; }
+run1 ising C 6 33 20 2
+run1 ising C 16 51 32 2
+run1 ising C 64 51 32 2
+run1 ising C 5 17 8 0
+run1 ising C 6 33 10 1
+run1 ising C 8 25 12 3
+run1 ising D 6 33 12 2
+run1 ising E 5 33 12 2
+run1 ising D 12 33 10 2
+run1 stdnorm 4 33 10 2
+run1 mvn 6 33 12 2
+runp 2 C 6 33 20 2
+runp 4 C 6 33 20 2
+runp 8 C 16 51 32 2
+runp 8 C 64 51 32 2
+runp 3 D 8 33 10 2
+# flang random_number stream (first 64 draws, hex) -- pins the RNG restatement
+cat > /tmp/ttx_rng.f90 <<'F'
+program rng
+ double precision :: d(64)
+ integer :: i
+ call random_number(d)
+ do i=1,64
+  write(*,'(z16.16)') d(i)
+ end do
+end program
+F
+amdflang -O2 /tmp/ttx_rng.f90 -o /tmp/ttx_rng.exe -Wl,-rpath,/opt/rocm/lib/llvm/lib && /tmp/ttx_rng.exe > $G/flang_rng.txt
