@@ -1,0 +1,128 @@
+/*
+ * ttx.h -- C-ABI of libttx.so, the MI355X-native engine for the reference's dtt_dmrgg greedy-cross sweep.
+ *
+ * The reference (aukeschaap/ttcross) has no FFI layer: its boundary for this path is the Fortran module
+ * interface of lib/dmrgg.f90 / lib/tt.f90 that the test_crs_* drivers `use`.  Each entry point below names
+ * the reference interface it replaces; INTEGRATION.md shows the ISO_C_BINDING stubs with which the
+ * reference's own modules (or the drop-in modules in ttcross_amd/fortran/) bind to them.
+ *
+ * Plain C types only (no torch / HIP types); every function returns 0 on success, a TTX_E* code
+ * otherwise, and ttx_last_error() gives the message (the Fortran shim turns it into the reference's
+ * `write(*,*) ...; stop`).  One host thread per engine handle.  The engine NEVER falls back to the CPU:
+ * without a gfx950 device ttx_create fails with TTX_ENODEV.
+ */
+#ifndef TTX_H
+#define TTX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTX_OK 0
+#define TTX_EINVAL 1   /* bad argument (reference: print + stop, e.g. lib/dmrgg.f90:88-91,114-117,590-592) */
+#define TTX_ENODEV 2   /* no usable HIP device                                                           */
+#define TTX_EHIP 3     /* HIP / RCCL runtime error                                                       */
+#define TTX_ESTATE 4   /* call out of order                                                              */
+
+/* built-in integrands (device code).  A user `fun` of the reference (lib/dmrgg.f90:18) cannot run on the
+ * GPU; the drivers' integrands are provided natively and selected by id. */
+#define TTX_FUN_ISING 1    /* dfunc_ising_discr, test_crs_ising.f90:176-218 (par(2n+1) = 1/2/3 -> C/D/E) */
+#define TTX_FUN_STDNORM 2  /* integrand, test_crs_stdnorm.f90:154-170                                     */
+#define TTX_FUN_MVN 3      /* integrand -> mvn_pdf, test_crs_mvn.f90:156-172, lib/mvn_pdf.f90:63-83       */
+
+typedef struct ttx_engine ttx_engine;
+
+/* Arguments of dtt_dmrgg(arg, fun, par, accuracy, maxrank, mybonds, pivoting, neval, quad, tru),
+ * lib/dmrgg.f90:11-26.  arg%l is always 1 (as in every driver); arg%m = d; arg%n = n[]. */
+typedef struct ttx_config {
+    int32_t d;              /* arg%m : number of TT cores                                            */
+    const int32_t *n;       /* arg%n(1:d) : mode sizes                                               */
+    int32_t fun_id;         /* TTX_FUN_* : replaces the `fun` callback                               */
+    const double *par;      /* par(*) as the driver builds it (nodes, weights, id)                   */
+    int32_t npar;
+    const double *aux;      /* TTX_FUN_MVN: mu[d], inv_cov[d*d] column-major, det (mvn_data)         */
+    int32_t naux;
+    const double *quadw;    /* quad : rank-1 TT of per-mode weights, d blocks of n[k]; NULL = absent */
+    double accuracy;        /* < 0 : absent                                                          */
+    int32_t maxrank;        /* required (>= 1): also sizes device storage                            */
+    int32_t pivoting;       /* -1 full, 0 lottery only, p >= 1 rook (reference default 3)            */
+    double tru;             /* tru (only used for the `err` column)                                  */
+    int32_t has_tru;
+    int32_t nproc;          /* total number of bond groups ("MPI ranks" of the reference), >= 1, < d */
+    const int32_t *mybonds; /* own(0:nproc), 1-based bonds; NULL -> share(1, d-1) lib/default.f90:78 */
+    int32_t device;         /* HIP device ordinal                                                    */
+    int32_t world_rank;     /* this process within the multi-GPU job (0 when single process)         */
+    int32_t world_size;     /* number of processes (GPUs); groups are split contiguously over them   */
+    int32_t verbose;        /* 1: print the reference's per-sweep log lines (lib/dmrgg.f90:971-1008) */
+    int32_t use_graph;      /* 1: replay each sweep as a captured hipGraph                           */
+} ttx_config;
+
+/* one line of the reference's per-sweep report (lib/dmrgg.f90:971-1008) */
+typedef struct ttx_sweep_rec {
+    int32_t it;
+    int32_t dir;            /* 0 '::', 1 '>>', 2 '<<' */
+    double erank;
+    int64_t neval;
+    double val;
+    double amax, pivotmax, pivotmin;
+    double seconds;         /* since the start of ttx_run */
+} ttx_sweep_rec;
+
+const char *ttx_last_error(void);
+int ttx_version(void);
+
+/* allocate device state for one dtt_dmrgg problem (replaces the implicit set-up of lib/dmrgg.f90:58-148) */
+int ttx_create(ttx_engine **out, const ttx_config *cfg);
+void ttx_destroy(ttx_engine *h);
+
+/* RCCL bootstrap for world_size > 1 (replaces mpi_init / MPI_COMM_WORLD, test_crs_ising.f90:31-36):
+ * rank 0 calls ttx_comm_unique_id, the host layer broadcasts the 128 bytes, every rank calls ttx_comm_init. */
+int ttx_comm_unique_id(uint8_t id[128]);
+int ttx_comm_init(ttx_engine *h, const uint8_t id[128]);
+
+/* dtt_dmrgg itself: initial cross, sweeps until maxrank / 3 strikes, finalisation dtt_lua (lib/dmrgg.f90:151-1049) */
+int ttx_run(ttx_engine *h);
+
+/* results */
+int ttx_num_sweeps(const ttx_engine *h);                          /* records available (sweep 0 included) */
+int ttx_get_sweeps(const ttx_engine *h, ttx_sweep_rec *out, int cap);
+int ttx_get_tapes(const ttx_engine *h, int32_t *out /* [nsweeps-1][d+1][4] */, int64_t cap);
+int64_t ttx_neval(const ttx_engine *h);                           /* `neval` of dtt_dmrgg                 */
+double ttx_seconds(const ttx_engine *h);                          /* wall time of the last ttx_run        */
+int ttx_get_ranks(const ttx_engine *h, int32_t *r /* [d+1] */);   /* arg%r(0:d)                           */
+int64_t ttx_core_size(const ttx_engine *h, int k);                /* r(k-1)*n(k)*r(k) or 0 if not owned   */
+int ttx_get_core(const ttx_engine *h, int k, double *buf);        /* arg%u(k)%p, column-major, k = 1..d   */
+
+/* dtt_quad(arg, quad) on the finalised cores (lib/dmrgg.f90:1261-1415); w = d blocks of n[k] weights, NULL = sum */
+int ttx_quad(ttx_engine *h, const double *w, double *val);
+
+/* profiling: with on != 0 the next ttx_run brackets every kernel launch with HIP events on the engine's
+ * stream; ttx_kernel_stats then reports, per kernel kind, launches and total milliseconds. */
+#define TTX_K_LOTTERY 0
+#define TTX_K_HALFSTEP 1   /* fiber evaluation + residual + argmax (the north star's "maxvol" kernel) */
+#define TTX_K_ACCEPT 2
+#define TTX_K_EXCHANGE 3
+#define TTX_K_QUAD 4
+#define TTX_K_OTHER 5
+#define TTX_K_NKINDS 6
+int ttx_set_profile(ttx_engine *h, int on);
+int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double ms[TTX_K_NKINDS], double bytes[TTX_K_NKINDS]);
+
+/* ---- kernel-level entry points used by the parity tests (host buffers in, host buffers out) ---- */
+
+/* K2: residual + first-argmax of one rook half-step (lib/dmrgg.f90:537-546 / 570-579):
+ * b = a - F*x in netlib dgemv order, F = m x r column-major (ld m); returns 0-based argmax and b[argmax]. */
+int ttx_k_residual_argmax(int32_t device, int32_t m, int32_t r, const double *a, const double *F, const double *x,
+                          double *b_out, int32_t *imax, double *bmax);
+/* K1: batch integrand evaluation, ind = npts x d (row-major, 1-based indices) */
+int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
+               const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out);
+/* lottery2 (lib/rnd.f90:105-126) with unit weights except zero at the listed 1-based positions */
+int ttx_k_lottery(int32_t device, int32_t npnt, int32_t m, int32_t n, int32_t nz, const int32_t *zcol,
+                  const int32_t *zrow, uint64_t rngpos, int32_t *points /* [2*npnt] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,570 @@
+// ttx_engine.hip -- host orchestration + C-ABI (include/ttx.h) of the MI355X TT-cross engine.
+//
+// One engine = one dtt_dmrgg problem (reference lib/dmrgg.f90:11-1050).  The sweep is a stream-ordered
+// chain of kernels with NO host round trip inside a sweep: the data-dependent control flow of the rook
+// loop (lib/dmrgg.f90:516-582) lives in device-side step states that each kernel resolves from the
+// previous kernel's partial arg-max records.  The host synchronises once per sweep to read the
+// reference's per-sweep report line and to apply the stop rule (lib/dmrgg.f90:1010-1019).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ttx.h"
+#include "ttx_kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(TTX_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" const char *ttx_last_error(void) { return g_err.c_str(); }
+extern "C" int ttx_version(void) { return 1; }
+
+struct HostOut { double amax, pivotmax, pivotmin, val, initval, bytes_half; long long neval, n_resid; };
+
+struct ttx_engine {
+    ttx_config cfg;
+    std::vector<int32_t> n1;            // 1-based n, size d+2
+    std::vector<double> par, aux, quadw;
+    std::vector<int32_t> own;           // own[0..nproc]
+    int d = 0, RM = 0, NM = 0, G = 0, NC = 0, nbmax = 0, H = 0, mode = 0;
+    int g0 = 0;                         // first global group held by this process
+    DevProb P{};
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    HostOut *h_out = nullptr;           // pinned [G]
+    int32_t *h_r = nullptr, *h_tape = nullptr;   // pinned
+    HostOut *d_out = nullptr;
+    std::vector<ttx_sweep_rec> recs;
+    std::vector<int32_t> tapes;         // [nsweeps-1][d+1][4]
+    std::vector<int32_t> rfinal;
+    int64_t neval = 0;
+    double seconds = 0.0;
+    bool ran = false;
+    // profiling
+    bool profile = false;
+    struct Ev { int kind; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    std::vector<hipEvent_t> evpool;
+    int64_t k_launches[TTX_K_NKINDS] = {0};
+    double k_ms[TTX_K_NKINDS] = {0}, k_bytes[TTX_K_NKINDS] = {0};
+    size_t lds_half = 0, lds_lot = 0, lds_par = 0;
+};
+
+template <class T>
+static int dev_alloc(ttx_engine *h, T **p, size_t count)
+{
+    void *q = nullptr;
+    HIPCHECK(hipMalloc(&q, count * sizeof(T) + 64));
+    HIPCHECK(hipMemset(q, 0, count * sizeof(T) + 64));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return TTX_OK;
+}
+
+// lib/default.f90:78-97 share(): own(p) = first + int(dble(last-first+1)*dble(p)/nproc)
+static void share(int first, int last, int nproc, std::vector<int32_t> &own)
+{
+    own.assign(nproc + 1, 0);
+    own[0] = first;
+    for (int p = 1; p < nproc; p++) own[p] = first + (int)((double)(last - first + 1) * (double)p / nproc);
+    own[nproc] = last + 1;
+}
+
+static double powi(double a, int b)
+{
+    double r = 1.0;
+    for (;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; }
+    return r;
+}
+
+extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
+{
+    if (!out || !cfg) return fail(TTX_EINVAL, "ttx_create: null argument");
+    *out = nullptr;
+    if (cfg->d < 2) return fail(TTX_EINVAL, "dtt_dmrgg: l,m: 1 %d", cfg->d);
+    if (cfg->maxrank < 1 || cfg->maxrank > 128) return fail(TTX_EINVAL, "ttx_create: maxrank must be in 1..128 (got %d)", cfg->maxrank);
+    if (cfg->pivoting < 0) return fail(TTX_EINVAL, "dtt_dmrgg: pivoting %d (full superblock search) is not available in this build", cfg->pivoting);
+    if (2 * cfg->pivoting + 2 > TTX_MAXH) return fail(TTX_EINVAL, "dtt_dmrgg: pivoting %d too large", cfg->pivoting);
+    if (cfg->fun_id < 1 || cfg->fun_id > 3) return fail(TTX_EINVAL, "ttx_create: unknown fun_id %d", cfg->fun_id);
+    const int nproc = cfg->nproc < 1 ? 1 : cfg->nproc;
+    if (nproc >= cfg->d) return fail(TTX_EINVAL, "nproc exceeds or equal dimension, cannot proceed");   // lib/dmrgg.f90:114-117
+    if (cfg->world_size > 1) return fail(TTX_EINVAL, "ttx_create: world_size > 1 needs ttx_comm_init (not in this build yet)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "ttx_create: no HIP device (the engine has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(TTX_ENODEV, "ttx_create: device %d not present", cfg->device);
+    HIPCHECK(hipSetDevice(cfg->device));
+
+    ttx_engine *h = new ttx_engine();
+    h->cfg = *cfg;
+    h->cfg.nproc = nproc;
+    const int d = cfg->d;
+    h->d = d; h->RM = cfg->maxrank;
+    h->n1.assign(d + 2, 1);
+    int NM = 1;
+    for (int k = 1; k <= d; k++) { h->n1[k] = cfg->n[k - 1]; if (cfg->n[k - 1] < 1 || cfg->n[k - 1] > 32000) { delete h; return fail(TTX_EINVAL, "bad mode size"); } NM = std::max(NM, cfg->n[k - 1]); }
+    h->NM = NM;
+    if ((long long)h->RM * NM > (long long)TTX_MAXPART * TTX_BLK) { delete h; return fail(TTX_EINVAL, "maxrank*n too large"); }
+    h->par.assign(cfg->par, cfg->par + cfg->npar);
+    if (cfg->aux && cfg->naux > 0) h->aux.assign(cfg->aux, cfg->aux + cfg->naux);
+    if (cfg->mybonds) h->own.assign(cfg->mybonds, cfg->mybonds + nproc + 1);
+    else share(1, d - 1, nproc, h->own);                               // lib/dmrgg.f90:126-130
+    for (int g = 0; g < nproc; g++) if (h->own[g + 1] <= h->own[g]) { delete h; return fail(TTX_EINVAL, "mybonds: empty group %d", g); }
+    h->G = nproc; h->g0 = 0;
+    h->nbmax = 0;
+    for (int g = 0; g < nproc; g++) h->nbmax = std::max(h->nbmax, h->own[g + 1] - h->own[g]);
+    h->NC = h->nbmax + 1;
+    h->mode = (cfg->pivoting == 0) ? 1 : 0;
+    h->H = (cfg->pivoting == 0) ? 2 : 2 * cfg->pivoting;
+    HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+    DevProb &P = h->P;
+    P.d = d; P.RM = h->RM; P.NM = NM; P.G = h->G; P.NC = h->NC;
+    P.fun_id = cfg->fun_id; P.piv = cfg->pivoting; P.npar = cfg->npar; P.nprocs = nproc;
+    P.ising_id = (cfg->fun_id == TTX_FUN_ISING) ? (int)cfg->par[2 * cfg->n[0]] : 0;
+    P.has_quad = cfg->quadw != nullptr;
+    P.small_element = 10 * 2.220446049250313e-16; P.small_pivot = 1.e-5;   // lib/dmrgg.f90:70-71
+    P.mvn_norm = 1.0;
+    if (cfg->fun_id == TTX_FUN_MVN) {
+        if (cfg->naux < d + d * d + 1) { delete h; return fail(TTX_EINVAL, "mvn: aux too short"); }
+        P.mvn_norm = std::sqrt(powi(2.0 * 3.141592653589793, d) * cfg->aux[d + (size_t)d * d]);   // lib/mvn_pdf.f90:82
+    }
+    P.SS = (size_t)h->RM * NM; P.SW = (size_t)NM * h->RM; P.CS = (size_t)h->RM * NM * h->RM;
+    const size_t G = h->G, NC = h->NC, RM = h->RM;
+    int rc;
+    int *dn; double *dpar, *daux = nullptr, *dq = nullptr;
+#define A_(call) if ((rc = (call)) != TTX_OK) { ttx_destroy(h); return rc; }
+    A_(dev_alloc(h, &dn, d + 2));
+    A_(dev_alloc(h, &dpar, cfg->npar + 1));
+    HIPCHECK(hipMemcpy(dn, h->n1.data(), sizeof(int) * (d + 2), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dpar, h->par.data(), sizeof(double) * cfg->npar, hipMemcpyHostToDevice));
+    if (!h->aux.empty()) { A_(dev_alloc(h, &daux, h->aux.size())); HIPCHECK(hipMemcpy(daux, h->aux.data(), sizeof(double) * h->aux.size(), hipMemcpyHostToDevice)); }
+    if (cfg->quadw) {
+        h->quadw.assign((size_t)(d + 1) * NM, 0.0);
+        size_t off = 0;
+        for (int k = 1; k <= d; k++) { for (int j = 0; j < h->n1[k]; j++) h->quadw[(size_t)k * NM + j] = cfg->quadw[off + j]; off += h->n1[k]; }
+        A_(dev_alloc(h, &dq, h->quadw.size()));
+        HIPCHECK(hipMemcpy(dq, h->quadw.data(), sizeof(double) * h->quadw.size(), hipMemcpyHostToDevice));
+    }
+    P.n = dn; P.par = dpar; P.aux = daux; P.quadw = dq;
+    A_(dev_alloc(h, &P.arg, G * NC * P.CS)); A_(dev_alloc(h, &P.col, G * NC * P.CS)); A_(dev_alloc(h, &P.row, G * NC * P.CS));
+    A_(dev_alloc(h, &P.inv, G * NC * RM * RM)); A_(dev_alloc(h, &P.vip, G * NC * 4 * RM));
+    A_(dev_alloc(h, &P.L, G * NC * d * RM)); A_(dev_alloc(h, &P.R, G * NC * d * RM));
+    A_(dev_alloc(h, &P.r, G * (d + 2))); A_(dev_alloc(h, &P.rr, G * (d + 2))); A_(dev_alloc(h, &P.upd, G * (d + 2))); A_(dev_alloc(h, &P.tape, G * (d + 2) * 4));
+    A_(dev_alloc(h, &P.acol, G * RM * NM)); A_(dev_alloc(h, &P.arow, G * RM * NM));
+    A_(dev_alloc(h, &P.Tq, G * NC * RM * RM)); A_(dev_alloc(h, &P.qpart, G * RM * RM));
+    A_(dev_alloc(h, &P.ind0, d + 2)); A_(dev_alloc(h, &P.gs, G));
+    A_(dev_alloc(h, &h->d_out, G));
+#undef A_
+    HIPCHECK(hipHostMalloc((void **)&h->h_out, sizeof(HostOut) * G));
+    HIPCHECK(hipHostMalloc((void **)&h->h_r, sizeof(int32_t) * G * (d + 2)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_tape, sizeof(int32_t) * G * (d + 2) * 4));
+    h->lds_par = sizeof(double) * (cfg->npar + 2);
+    h->lds_half = sizeof(double) * (cfg->npar + RM + 2) + sizeof(int) * (d + 4) + sizeof(short) * ((size_t)d * RM + 8);
+    h->lds_lot = sizeof(double) * (cfg->npar + 2 * RM + 2 * NM + 2) + sizeof(int) * 4 * (2 * RM + 2 * NM + 2);
+    if (h->lds_half > 160 * 1024 || h->lds_lot > 64 * 1024) { ttx_destroy(h); return fail(TTX_EINVAL, "problem too large for LDS staging (d*maxrank)"); }
+    *out = h;
+    return TTX_OK;
+}
+
+extern "C" void ttx_destroy(ttx_engine *h)
+{
+    if (!h) return;
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->h_r) (void)hipHostFree(h->h_r);
+    if (h->h_tape) (void)hipHostFree(h->h_tape);
+    for (auto &e : h->evpool) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int ttx_comm_unique_id(uint8_t id[128]) { (void)id; return fail(TTX_ESTATE, "ttx_comm_unique_id: RCCL transport not built yet"); }
+extern "C" int ttx_comm_init(ttx_engine *h, const uint8_t id[128]) { (void)h; (void)id; return fail(TTX_ESTATE, "ttx_comm_init: RCCL transport not built yet"); }
+
+// ---- launch helpers -------------------------------------------------------------------------------
+static hipEvent_t ev_get(ttx_engine *h)
+{
+    if (!h->evpool.empty()) { hipEvent_t e = h->evpool.back(); h->evpool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct KScope {
+    ttx_engine *h; int kind; hipEvent_t a = nullptr, b = nullptr;
+    KScope(ttx_engine *h_, int kind_) : h(h_), kind(kind_) { if (h->profile) { a = ev_get(h); b = ev_get(h); (void)hipEventRecord(a, h->stream); } }
+    ~KScope() { if (h->profile) { (void)hipEventRecord(b, h->stream); h->evs.push_back({kind, a, b}); } else h->k_launches[kind]++; }
+};
+static void ev_collect(ttx_engine *h)
+{
+    for (auto &e : h->evs) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e.a, e.b);
+        h->k_ms[e.kind] += ms; h->k_launches[e.kind]++;
+        h->evpool.push_back(e.a); h->evpool.push_back(e.b);
+    }
+    h->evs.clear();
+}
+
+__global__ void k_collect(DevProb P, HostOut *out)
+{
+    int g = blockIdx.x;
+    if (threadIdx.x) return;
+    const GroupState &gs = P.gs[g];
+    HostOut o;
+    o.amax = gs.amax; o.pivotmax = gs.pivotmax; o.pivotmin = gs.pivotmin; o.val = gs.val; o.initval = gs.initval;
+    o.neval = gs.neval; o.bytes_half = 0.0; o.n_resid = 0;
+    out[g] = o;
+}
+
+template <int FUN>
+static int run_impl(ttx_engine *h);
+
+static double erank_host(const ttx_engine *h, const int32_t *r)
+{
+    // lib/tt.f90:1228-1245
+    const int l = 1, m = h->d, d = m;
+    if (d == 1) return 0.0;
+    double s = 0.0;
+    for (int i = l; i <= m; i++) s = s + r[i - 1] * h->n1[i] * r[i];
+    if (s == 0.0) return s;
+    int b = r[l - 1] * h->n1[l] + h->n1[m] * r[m];
+    if (d == 2) return s / b;
+    int a = 0;
+    for (int i = l + 1; i <= m - 1; i++) a += h->n1[i];
+    return (std::sqrt(b * b + 4.0 * a * s) - b) / (2.0 * a);
+}
+
+// Fortran Ew.d for non-negative values
+static std::string fmt_e(int w, int dgt, double v)
+{
+    char tmp[64], body[64];
+    if (v != 0.0 && std::isfinite(v)) {
+        snprintf(tmp, sizeof tmp, "%.*e", dgt - 1, v);
+        char *e = strchr(tmp, 'e');
+        int ex = atoi(e + 1) + 1;
+        *e = 0;
+        std::string digs;
+        for (char *c = tmp; *c; c++) if (*c >= '0' && *c <= '9') digs.push_back(*c);
+        snprintf(body, sizeof body, ".%sE%c%02d", digs.c_str(), ex < 0 ? '-' : '+', abs(ex));
+    } else snprintf(body, sizeof body, ".%sE+00", std::string(dgt, '0').c_str());
+    std::string s = body;
+    if ((int)s.size() + 1 <= w) s = "0" + s;
+    if ((int)s.size() < w) s = std::string(w - s.size(), ' ') + s;
+    return s;
+}
+
+static void print_line(const ttx_engine *h, const ttx_sweep_rec &r, double val_prev)
+{
+    // lib/dmrgg.f90:971-1008
+    const char *sd = r.dir == 0 ? "::" : r.dir == 1 ? ">>" : "<<";
+    printf("%3d%2s rank%5.1f time: %s n_evals: %10lld", r.it, sd, r.erank, fmt_e(9, 3, r.seconds).c_str(), (long long)r.neval);
+    if (h->P.has_quad) {
+        if (r.it == 0) printf(" val %s", fmt_e(20, 14, r.val).c_str());
+        else if (h->cfg.has_tru) printf(" err %s val %s", fmt_e(8, 3, std::fabs(1.0 - r.val / h->cfg.tru)).c_str(), fmt_e(20, 14, r.val).c_str());
+        else printf(" cnv %s val %s", fmt_e(8, 3, std::fabs(1.0 - r.val / val_prev)).c_str(), fmt_e(20, 14, r.val).c_str());
+    }
+    printf("\n");
+    fflush(stdout);
+}
+
+static int readback(ttx_engine *h)
+{
+    const size_t G = h->G, d = h->d;
+    hipLaunchKernelGGL(k_collect, dim3(h->G), dim3(64), 0, h->stream, h->P, h->d_out);
+    HIPCHECK(hipMemcpyAsync(h->h_out, h->d_out, sizeof(HostOut) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->h_r, h->P.r, sizeof(int32_t) * G * (d + 2), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->h_tape, h->P.tape, sizeof(int32_t) * G * (d + 2) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->profile) ev_collect(h);
+    return TTX_OK;
+}
+
+template <int FUN>
+static int run_impl(ttx_engine *h)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    auto since = [&]() { return std::chrono::duration<double>(clk::now() - t0).count(); };
+    DevProb &P = h->P;
+    const int d = h->d, G = h->G, nproc = h->cfg.nproc;
+    hipStream_t st = h->stream;
+    h->recs.clear(); h->tapes.clear();
+
+    // ---- reset state (lib/dmrgg.f90:96-100, 141-148, 279-288) ----
+    {
+        std::vector<GroupState> gs(G);
+        memset(gs.data(), 0, sizeof(GroupState) * G);
+        for (int g = 0; g < G; g++) { gs[g].first = h->own[h->g0 + g]; gs[g].last = h->own[h->g0 + g + 1] - 1; gs[g].gglobal = h->g0 + g; gs[g].pivotmax = -1.0; gs[g].pivotmin = -1.0; }
+        HIPCHECK(hipMemcpyAsync(P.gs, gs.data(), sizeof(GroupState) * G, hipMemcpyHostToDevice, st));
+        std::vector<int32_t> ones((size_t)G * (d + 2), 1), m1((size_t)G * (d + 2) * 4, -1);
+        HIPCHECK(hipMemcpyAsync(P.r, ones.data(), sizeof(int32_t) * ones.size(), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(P.rr, ones.data(), sizeof(int32_t) * ones.size(), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(P.tape, m1.data(), sizeof(int32_t) * m1.size(), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemsetAsync(P.upd, 0, sizeof(int32_t) * (size_t)G * (d + 2), st));
+        HIPCHECK(hipStreamSynchronize(st));   // host vectors go out of scope
+    }
+    // ---- initial cross (:151-301) ----
+    const int smin = 8, snum = std::max(smin, nproc);
+    int nn = h->n1[1];
+    for (int k = 2; k <= d; k++) nn = std::min(nn, h->n1[k]);
+    {
+        KScope ks(h, TTX_K_OTHER);
+        hipLaunchKernelGGL(k_init_samples<FUN>, dim3(G), dim3(256), h->lds_par, st, P, snum, nn, 0, 0);
+    }
+    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_init_fibers<FUN>, dim3(h->NC, G), dim3(256), h->lds_par, st, P); }
+    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), 0, st, P); }
+    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_init_final, dim3(G), dim3(64), 0, st, P); }
+    int rc = readback(h);
+    if (rc) return rc;
+    HIPCHECK(hipGetLastError());
+    double val = 1.0, val_prev = 1.0;
+    for (int g = 0; g < G; g++) val = (g == 0) ? h->h_out[g].initval : val * h->h_out[g].initval;   // :259-267 PROD
+    if (!P.has_quad) val = 0.0;
+    val_prev = val;
+    auto total_neval = [&]() { long long s = 0; for (int g = 0; g < G; g++) s += h->h_out[g].neval; return s; };
+    {
+        ttx_sweep_rec r{};
+        r.it = 0; r.dir = 0; r.erank = erank_host(h, h->h_r); r.neval = total_neval(); r.val = val;
+        r.amax = h->h_out[0].amax; r.pivotmax = -1; r.pivotmin = -1; r.seconds = since();
+        h->recs.push_back(r);
+        if (h->cfg.verbose) print_line(h, r, val_prev);
+    }
+
+    // ---- main loop (:309-1020) ----
+    int it = 0, strike = 0;
+    bool ready = (it + 1 >= h->cfg.maxrank);
+    const int nfb = (h->RM * h->NM + TTX_BLK - 1) / TTX_BLK;
+    const size_t lds_acc = sizeof(double) * (h->RM + 2);
+    const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
+    while (!ready) {
+        it++;
+        const int dir = 2 - it % 2;
+        for (int pp = 1; pp <= h->nbmax; pp++) {
+            { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp); }
+            for (int hh = 0; hh < h->H; hh++) {
+                KScope ks(h, TTX_K_HALFSTEP);
+                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode);
+            }
+            { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
+        }
+        { KScope ks(h, TTX_K_EXCHANGE); hipLaunchKernelGGL(k_sweep_end, dim3(G), dim3(64), 0, st, P); }
+        if (P.has_quad) {
+            KScope ks(h, TTX_K_QUAD);
+            hipLaunchKernelGGL(k_quad_build, dim3(h->NC, G), dim3(256), lds_q, st, P, 0, P.quadw);
+            hipLaunchKernelGGL(k_quad_chain, dim3(G), dim3(256), 2 * lds_q, st, P);
+        }
+        rc = readback(h);
+        if (rc) return rc;
+        HIPCHECK(hipGetLastError());
+        if (P.has_quad) val = h->h_out[0].val;
+        ttx_sweep_rec r{};
+        r.it = it; r.dir = dir; r.erank = erank_host(h, h->h_r); r.neval = total_neval(); r.val = val;
+        r.amax = h->h_out[0].amax; r.pivotmax = h->h_out[0].pivotmax; r.pivotmin = h->h_out[0].pivotmin; r.seconds = since();
+        h->recs.push_back(r);
+        {
+            size_t o = h->tapes.size();
+            h->tapes.resize(o + (size_t)(d + 1) * 4, -1);
+            for (int g = 0; g < G; g++)
+                for (int p = h->own[h->g0 + g]; p < h->own[h->g0 + g + 1]; p++)
+                    memcpy(&h->tapes[o + (size_t)p * 4], &h->h_tape[((size_t)g * (d + 2) + p) * 4], sizeof(int32_t) * 4);
+        }
+        if (h->cfg.verbose) print_line(h, r, val_prev);
+        val_prev = val;
+        ready = ready || (it + 1 >= h->cfg.maxrank);                              // :1011
+        if (h->cfg.accuracy >= 0.0) {                                             // :1012-1019
+            if (r.pivotmax <= h->cfg.accuracy * r.amax) strike++; else strike = 0;
+            ready = ready || (strike >= 3);
+        }
+    }
+    // ---- finalise (:1029) ----
+    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), 0, st, P); }
+    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), 0, st, P); }
+    rc = readback(h);
+    if (rc) return rc;
+    HIPCHECK(hipGetLastError());
+    h->neval = total_neval();
+    h->rfinal.assign(h->h_r, h->h_r + d + 1);
+    h->seconds = since();
+    h->ran = true;
+    return TTX_OK;
+}
+
+extern "C" int ttx_run(ttx_engine *h)
+{
+    if (!h) return fail(TTX_EINVAL, "ttx_run: null handle");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
+    switch (h->cfg.fun_id) {
+        case TTX_FUN_ISING: return run_impl<FUN_ISING>(h);
+        case TTX_FUN_STDNORM: return run_impl<FUN_STDNORM>(h);
+        default: return run_impl<FUN_MVN>(h);
+    }
+}
+
+extern "C" int ttx_num_sweeps(const ttx_engine *h) { return h ? (int)h->recs.size() : 0; }
+extern "C" int ttx_get_sweeps(const ttx_engine *h, ttx_sweep_rec *out, int cap)
+{
+    if (!h || !out) return fail(TTX_EINVAL, "ttx_get_sweeps: null argument");
+    int n = std::min(cap, (int)h->recs.size());
+    memcpy(out, h->recs.data(), sizeof(ttx_sweep_rec) * n);
+    return TTX_OK;
+}
+extern "C" int ttx_get_tapes(const ttx_engine *h, int32_t *out, int64_t cap)
+{
+    if (!h || !out) return fail(TTX_EINVAL, "ttx_get_tapes: null argument");
+    int64_t n = std::min<int64_t>(cap, (int64_t)h->tapes.size());
+    memcpy(out, h->tapes.data(), sizeof(int32_t) * n);
+    return TTX_OK;
+}
+extern "C" int64_t ttx_neval(const ttx_engine *h) { return h ? h->neval : 0; }
+extern "C" double ttx_seconds(const ttx_engine *h) { return h ? h->seconds : 0.0; }
+extern "C" int ttx_get_ranks(const ttx_engine *h, int32_t *r)
+{
+    if (!h || !r || !h->ran) return fail(TTX_ESTATE, "ttx_get_ranks: run first");
+    memcpy(r, h->rfinal.data(), sizeof(int32_t) * (h->d + 1));
+    return TTX_OK;
+}
+static int owner_of_core(const ttx_engine *h, int k)
+{
+    for (int g = 0; g < h->G; g++) {
+        int first = h->own[h->g0 + g], last = h->own[h->g0 + g + 1] - 1;
+        bool lastg = (h->g0 + g == h->cfg.nproc - 1);
+        if (k >= first && (k <= last || (lastg && k == h->d))) return g;
+    }
+    return -1;
+}
+extern "C" int64_t ttx_core_size(const ttx_engine *h, int k)
+{
+    if (!h || !h->ran || k < 1 || k > h->d || owner_of_core(h, k) < 0) return 0;
+    return (int64_t)h->rfinal[k - 1] * h->n1[k] * h->rfinal[k];
+}
+extern "C" int ttx_get_core(const ttx_engine *h, int k, double *buf)
+{
+    if (!h || !buf || !h->ran) return fail(TTX_ESTATE, "ttx_get_core: run first");
+    if (k < 1 || k > h->d) return fail(TTX_EINVAL, "ttx_get_core: core %d out of range", k);
+    int g = owner_of_core(h, k);
+    if (g < 0) return fail(TTX_EINVAL, "ttx_get_core: core %d is not held by this process", k);
+    const int r0 = h->rfinal[k - 1], r1 = h->rfinal[k], n = h->n1[k], first = h->own[h->g0 + g];
+    const double *src = h->P.arg + ((size_t)g * h->NC + (k - first)) * h->P.CS;
+    // strided device -> compact host: one 2D copy per right-rank slab (pure data movement)
+    for (int s = 0; s < r1; s++)
+        HIPCHECK(hipMemcpy2D(buf + (size_t)r0 * n * s, sizeof(double) * r0, src + h->P.SS * s, sizeof(double) * h->RM, sizeof(double) * r0, n, hipMemcpyDeviceToHost));
+    return TTX_OK;
+}
+
+extern "C" int ttx_quad(ttx_engine *h, const double *w, double *val)
+{
+    if (!h || !val || !h->ran) return fail(TTX_ESTATE, "ttx_quad: run first");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    double *dw = nullptr;
+    std::vector<double> wp;
+    if (w) {
+        wp.assign((size_t)(h->d + 1) * h->NM, 0.0);
+        size_t off = 0;
+        for (int k = 1; k <= h->d; k++) { for (int j = 0; j < h->n1[k]; j++) wp[(size_t)k * h->NM + j] = w[off + j]; off += h->n1[k]; }
+        HIPCHECK(hipMalloc((void **)&dw, sizeof(double) * wp.size()));
+        HIPCHECK(hipMemcpy(dw, wp.data(), sizeof(double) * wp.size(), hipMemcpyHostToDevice));
+    }
+    const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
+    hipLaunchKernelGGL(k_quad_build, dim3(h->NC, h->G), dim3(256), lds_q, h->stream, h->P, 1, (const double *)dw);
+    hipLaunchKernelGGL(k_quad_chain, dim3(h->G), dim3(256), 2 * lds_q, h->stream, h->P);
+    int rc = readback(h);
+    if (dw) (void)hipFree(dw);
+    if (rc) return rc;
+    HIPCHECK(hipGetLastError());
+    *val = h->h_out[0].val;
+    return TTX_OK;
+}
+
+extern "C" int ttx_set_profile(ttx_engine *h, int on) { if (!h) return fail(TTX_EINVAL, "null"); h->profile = on != 0; return TTX_OK; }
+extern "C" int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double ms[TTX_K_NKINDS], double bytes[TTX_K_NKINDS])
+{
+    if (!h) return fail(TTX_EINVAL, "null");
+    for (int k = 0; k < TTX_K_NKINDS; k++) { launches[k] = h->k_launches[k]; ms[k] = h->k_ms[k]; bytes[k] = h->k_bytes[k]; }
+    return TTX_OK;
+}
+
+// ---- kernel-level test entry points ------------------------------------------------------------------
+extern "C" int ttx_k_residual_argmax(int32_t device, int32_t m, int32_t r, const double *a, const double *F, const double *x,
+                                     double *b_out, int32_t *imax, double *bmax)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "no HIP device");
+    HIPCHECK(hipSetDevice(device));
+    if (r > 256 || m < 1) return fail(TTX_EINVAL, "ttx_k_residual_argmax: bad sizes");
+    double *da, *dF, *dx, *db; Partial *dp;
+    int nb = (m + TTX_BLK - 1) / TTX_BLK;
+    HIPCHECK(hipMalloc((void **)&da, sizeof(double) * m)); HIPCHECK(hipMalloc((void **)&dF, sizeof(double) * (size_t)m * std::max(r, 1)));
+    HIPCHECK(hipMalloc((void **)&dx, sizeof(double) * std::max(r, 1))); HIPCHECK(hipMalloc((void **)&db, sizeof(double) * m));
+    HIPCHECK(hipMalloc((void **)&dp, sizeof(Partial) * nb));
+    HIPCHECK(hipMemcpy(da, a, sizeof(double) * m, hipMemcpyHostToDevice));
+    if (r > 0) { HIPCHECK(hipMemcpy(dF, F, sizeof(double) * (size_t)m * r, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(dx, x, sizeof(double) * r, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_resid_argmax, dim3(nb), dim3(TTX_BLK), 0, 0, m, r, (size_t)m, da, dF, dx, db, dp);
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<Partial> parts(nb);
+    HIPCHECK(hipMemcpy(parts.data(), dp, sizeof(Partial) * nb, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(b_out, db, sizeof(double) * m, hipMemcpyDeviceToHost));
+    double ba = -1; int bi = INT_MAX; double bv = 0;
+    for (auto &p : parts) if (p.absmax > ba || (p.absmax == ba && p.idx < bi)) { ba = p.absmax; bi = p.idx; bv = p.val; }
+    *imax = bi; *bmax = bv;
+    (void)hipFree(da); (void)hipFree(dF); (void)hipFree(dx); (void)hipFree(db); (void)hipFree(dp);
+    return TTX_OK;
+}
+
+extern "C" int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
+                          const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "no HIP device");
+    HIPCHECK(hipSetDevice(device));
+    DevProb P{};
+    std::vector<int> n1(d + 2, 1);
+    for (int k = 1; k <= d; k++) n1[k] = n[k - 1];
+    int *dn, *dind; double *dpar, *daux = nullptr, *dout;
+    HIPCHECK(hipMalloc((void **)&dn, sizeof(int) * (d + 2))); HIPCHECK(hipMalloc((void **)&dpar, sizeof(double) * npar));
+    HIPCHECK(hipMalloc((void **)&dind, sizeof(int) * npts * d)); HIPCHECK(hipMalloc((void **)&dout, sizeof(double) * npts));
+    HIPCHECK(hipMemcpy(dn, n1.data(), sizeof(int) * (d + 2), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dpar, par, sizeof(double) * npar, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dind, ind, sizeof(int) * npts * d, hipMemcpyHostToDevice));
+    if (aux && naux > 0) { HIPCHECK(hipMalloc((void **)&daux, sizeof(double) * naux)); HIPCHECK(hipMemcpy(daux, aux, sizeof(double) * naux, hipMemcpyHostToDevice)); }
+    P.d = d; P.n = dn; P.par = dpar; P.aux = daux; P.npar = npar; P.fun_id = fun_id;
+    P.ising_id = (fun_id == TTX_FUN_ISING) ? (int)par[2 * n[0]] : 0;
+    P.mvn_norm = (fun_id == TTX_FUN_MVN) ? std::sqrt(powi(2.0 * 3.141592653589793, d) * aux[d + (size_t)d * d]) : 1.0;
+    dim3 grid((unsigned)((npts + 255) / 256));
+    size_t lds = sizeof(double) * (npar + 2);
+    if (fun_id == TTX_FUN_ISING) hipLaunchKernelGGL(k_eval_list<FUN_ISING>, grid, dim3(256), lds, 0, P, (long long)npts, dind, dout);
+    else if (fun_id == TTX_FUN_STDNORM) hipLaunchKernelGGL(k_eval_list<FUN_STDNORM>, grid, dim3(256), lds, 0, P, (long long)npts, dind, dout);
+    else hipLaunchKernelGGL(k_eval_list<FUN_MVN>, grid, dim3(256), lds, 0, P, (long long)npts, dind, dout);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(out, dout, sizeof(double) * npts, hipMemcpyDeviceToHost));
+    (void)hipFree(dn); (void)hipFree(dpar); (void)hipFree(dind); (void)hipFree(dout); if (daux) (void)hipFree(daux);
+    return TTX_OK;
+}
+
+extern "C" int ttx_k_lottery(int32_t device, int32_t npnt, int32_t m, int32_t n, int32_t nz, const int32_t *zcol,
+                             const int32_t *zrow, uint64_t rngpos, int32_t *points)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "no HIP device");
+    HIPCHECK(hipSetDevice(device));
+    int *dzc, *dzr, *dp;
+    HIPCHECK(hipMalloc((void **)&dzc, sizeof(int) * (nz + 1))); HIPCHECK(hipMalloc((void **)&dzr, sizeof(int) * (nz + 1)));
+    HIPCHECK(hipMalloc((void **)&dp, sizeof(int) * 2 * npnt));
+    if (nz > 0) { HIPCHECK(hipMemcpy(dzc, zcol, sizeof(int) * nz, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(dzr, zrow, sizeof(int) * nz, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_lottery_only, dim3(1), dim3(256), 0, 0, npnt, m, n, nz, dzc, dzr, (unsigned long long)rngpos, dp);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(points, dp, sizeof(int) * 2 * npnt, hipMemcpyDeviceToHost));
+    (void)hipFree(dzc); (void)hipFree(dzr); (void)hipFree(dp);
+    return TTX_OK;
+}

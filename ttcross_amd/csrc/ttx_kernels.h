@@ -1,0 +1,796 @@
+// ttx_kernels.h -- CDNA4 (gfx950) kernels of the dtt_dmrgg sweep.  Included by ttx_engine.hip only.
+// Compiled with -ffp-contract=off: every product and sum below is an individual IEEE fp64 rounding, in the
+// order of the netlib reference BLAS the oracle restates, so pivot paths are reproducible bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include "ttx_cdf.h"
+#include "ttx_dev.h"
+
+#define FUN_ISING 1
+#define FUN_STDNORM 2
+#define FUN_MVN 3
+
+// ------------------------------------------------------------------------------------------------
+// address helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double *core_ptr(const DevProb &P, double *base, int g, int p, int first)
+{ return base + ((size_t)g * P.NC + (p - first)) * P.CS; }
+__device__ __forceinline__ double *inv_ptr(const DevProb &P, int g, int s, int first)   // bond s in first-1..last
+{ return P.inv + ((size_t)g * P.NC + (s - first + 1)) * (size_t)P.RM * P.RM; }
+__device__ __forceinline__ int *vip_ptr(const DevProb &P, int g, int s, int first)
+{ return P.vip + ((size_t)g * P.NC + (s - first + 1)) * (size_t)4 * P.RM; }
+__device__ __forceinline__ short *L_ptr(const DevProb &P, int g, int s, int first)      // bond s in first-1..last
+{ return P.L + ((size_t)g * P.NC + (s - first + 1)) * (size_t)P.d * P.RM; }
+__device__ __forceinline__ short *R_ptr(const DevProb &P, int g, int s, int first)      // bond s in first..last+1
+{ return P.R + ((size_t)g * P.NC + (s - first)) * (size_t)P.d * P.RM; }
+
+// ------------------------------------------------------------------------------------------------
+// integrands (reference drivers' callbacks).  idx(s), s = 1..m, returns the 1-based mode index of dim s.
+// ------------------------------------------------------------------------------------------------
+template <class IDX>
+__device__ __forceinline__ double f_ising(int id, int m, int n1, const double *par, IDX idx)
+{
+    // test_crs_ising.f90:176-218
+    const double *nodes = par - 1, *weights = par + n1 - 1;
+    double a = 1.0, b = 0.0, f;
+    if (id == 2 || id == 3) {
+        for (int i = 0; i <= m; i++) {
+            double uij = 1.0;
+            for (int j = i + 1; j <= m; j++) {
+                uij = uij * nodes[idx(j)];
+                double t = (uij - 1.0) / (uij + 1.0);
+                a = a * (t * t);
+            }
+        }
+    }
+    if (id == 1 || id == 2) {
+        double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
+        for (int i = 1; i <= m; i++) {
+            vk = vk * nodes[idx(m - i + 1)];
+            wk = wk * nodes[idx(i)];
+            v = v + vk;
+            w = w + wk;
+        }
+        b = 1.0 / (v * w);
+    }
+    f = (id == 1) ? 2 * b : (id == 2) ? 2 * a * b : 2 * a;
+    for (int i = 1; i <= m; i++) f = f * weights[idx(i)];
+    return f;
+}
+
+template <class IDX>
+__device__ __forceinline__ double f_stdnorm(int m, const double *par, IDX idx)
+{
+    // test_crs_stdnorm.f90:154-170
+    double s = 0.0;
+    for (int i = 1; i <= m; i++) { double x = par[idx(i) - 1]; s = s + x * x; }
+    return exp(-s);
+}
+
+template <class IDX>
+__device__ __forceinline__ double f_mvn(int m, const double *par, const double *aux, double norm, IDX idx)
+{
+    // test_crs_mvn.f90:156-172 + lib/mvn_pdf.f90:63-83
+    const double *mu = aux, *ic = aux + m;
+    double ex = 0.0;
+    for (int i = 1; i <= m; i++) {
+        double di = par[idx(i) - 1] - mu[i - 1];
+        for (int j = 1; j <= m; j++) {
+            double dj = par[idx(j) - 1] - mu[j - 1];
+            ex = ex + di * ic[(i - 1) + (size_t)m * (j - 1)] * dj;
+        }
+    }
+    return exp(-0.5 * ex) / norm;
+}
+
+template <int FUN, class IDX>
+__device__ __forceinline__ double eval_fun(const DevProb &P, const double *par, IDX idx)
+{
+    if (FUN == FUN_ISING) return f_ising(P.ising_id, P.d, P.n[1], par, idx);
+    if (FUN == FUN_STDNORM) return f_stdnorm(P.d, par, idx);
+    return f_mvn(P.d, par, P.aux, P.mvn_norm, idx);
+}
+
+// accessor over flattened tables: dims [vfrom, vto] from table vt (entry (s-vfrom)*vstride + vcol), dim
+// `self` = selfval, every other dim from fx[s]
+struct FiberIdx {
+    const short *vt; int vstride, vcol, vfrom, vto, self, selfval; const int *fx;
+    __device__ __forceinline__ int operator()(int s) const
+    { return (s == self) ? selfval : (s >= vfrom && s <= vto) ? (int)vt[(s - vfrom) * vstride + vcol] : fx[s]; }
+};
+// accessor for one superblock entry (i,j,k,q) at bond p straight from the global tables (dmrgg_fun)
+struct EntryIdx {
+    const short *Lt, *Rt; int RM, p, i, j, k, q;   // i,q 0-based pivot ids; j,k 1-based mode indices
+    __device__ __forceinline__ int operator()(int s) const
+    { return s < p ? (int)Lt[(s - 1) * RM + i] : (s == p) ? j : (s == p + 1) ? k : (int)Rt[(s - p - 2) * RM + q]; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ void wave_argmax(double &a, double &v, int &idx)
+{
+    // first-max rule of idamax: larger |.| wins, ties go to the lower index
+    for (int o = 32; o > 0; o >>= 1) {
+        double a2 = __shfl_xor(a, o, 64), v2 = __shfl_xor(v, o, 64);
+        int i2 = __shfl_xor(idx, o, 64);
+        if (a2 > a || (a2 == a && i2 < idx)) { a = a2; v = v2; idx = i2; }
+    }
+}
+// returns block max to every thread; sh must hold blockDim/64 doubles
+__device__ __forceinline__ double block_max(double v, double *sh)
+{
+    v = wave_max(v);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double r = sh[0];
+    for (int x = 1; x < nw; x++) r = fmax(r, sh[x]);
+    return r;
+}
+// block arg-max; result valid in thread 0; sha/shv/shi hold blockDim/64 entries
+__device__ __forceinline__ void block_argmax(double &a, double &v, int &idx, double *sha, double *shv, int *shi)
+{
+    wave_argmax(a, v, idx);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sha[w] = a; shv[w] = v; shi[w] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int x = 1; x < nw; x++)
+            if (sha[x] > a || (sha[x] == a && shi[x] < idx)) { a = sha[x]; v = shv[x]; idx = shi[x]; }
+}
+
+__device__ __forceinline__ void atomic_max_pos(double *addr, double v)
+{   // v >= 0: the IEEE bit patterns of non-negative doubles order like unsigned integers
+    atomicMax((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+// resolve pending partial arg-max records of the previous half-step into the step state
+// (lib/dmrgg.f90:540-546 and :573-579)
+__device__ inline void resolve_state(StepState &c, const Partial *pt)
+{
+    if (!c.active || !c.pending) return;
+    int nf = (c.pending == 1) ? c.r0 * c.n1 : c.n2 * c.r2;
+    int nb = (nf + TTX_BLK - 1) / TTX_BLK;
+    double ba = -1.0, bv = 0.0; int bi = INT_MAX;
+    for (int b = 0; b < nb; b++) {
+        double a = pt[b].absmax; int ix = pt[b].idx;
+        if (a > ba || (a == ba && ix < bi)) { ba = a; bv = pt[b].val; bi = ix; }
+    }
+    if (c.pending == 1) {
+        int i = bi % c.r0 + 1, j = bi / c.r0 + 1;
+        c.done = c.havecol && c.haverow && (i == c.ii && j == c.jj);
+        c.ii = i; c.jj = j;
+    } else {
+        int k = bi % c.n2 + 1, q = bi / c.n2 + 1;
+        c.done = c.havecol && c.haverow && (k == c.kk && q == c.qq);
+        c.kk = k; c.qq = q;
+    }
+    c.pivot = bv;
+    c.pending = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: initial cross (lib/dmrgg.f90:151-248)
+// ------------------------------------------------------------------------------------------------
+struct DiagIdx { const int *n; int k, s; __device__ __forceinline__ int operator()(int p) const { return (k - 1 + s * (p - 1)) % n[p] + 1; } };
+struct FixIdx { const int *ind; int self, selfval; __device__ __forceinline__ int operator()(int s) const { return s == self ? selfval : ind[s]; } };
+
+// every group evaluates all nn*snum shifted-diagonal samples (a few hundred) so that the MAXLOC of :196
+// needs no exchange; each group is charged only its own share of evaluations (:160,181)
+template <int FUN>
+__global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int nn, int shift_lo, int shift_hi)
+{
+    extern __shared__ double dyn[];
+    double *par = dyn;
+    __shared__ double sha[4], shv[4]; __shared__ int shi[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    GroupState &gs = P.gs[g];
+    for (int x = tid; x < P.npar; x += blockDim.x) par[x] = P.par[x];
+    __syncthreads();
+    double ba = -1.0, bv = 0.0; int bi = INT_MAX;
+    for (int il = tid; il < nn * snum; il += blockDim.x) {
+        DiagIdx ix{P.n, il % nn + 1, il / nn};
+        double f = eval_fun<FUN>(P, par, ix);
+        double a = fabs(f);
+        if (a > ba || (a == ba && il < bi)) { ba = a; bv = f; bi = il; }
+    }
+    block_argmax(ba, bv, bi, sha, shv, shi);
+    if (tid == 0) {
+        gs.amax = ba;                                             // :180,201
+        // :153-156 shifts(p) = int(dble(snum)*dble(p)/nproc); own share of the samples (:160,181)
+        int gg = gs.gglobal;
+        int lo = (int)((double)snum * (double)gg / P.nprocs);
+        int hi = (gg + 1 == P.nprocs) ? snum : (int)((double)snum * (double)(gg + 1) / P.nprocs);
+        gs.neval = (long long)nn * (hi - lo);
+        if (g == 0) {
+            int s = bi / nn, k = bi % nn + 1;
+            for (int p = 1; p <= P.d; p++) P.ind0[p] = (k - 1 + s * (p - 1)) % P.n[p] + 1;   // :205-209
+            P.ind0[P.d + 1] = 1;
+        }
+    }
+}
+
+// fibers through the initial index for own cores (:221-232)
+template <int FUN>
+__global__ __launch_bounds__(256) void k_init_fibers(DevProb P)
+{
+    extern __shared__ double dyn[];
+    double *par = dyn;
+    __shared__ double shm[4];
+    const int g = blockIdx.y, tid = threadIdx.x;
+    GroupState &gs = P.gs[g];
+    const int p = gs.first + blockIdx.x;
+    if (p > gs.last + 1) return;
+    for (int x = tid; x < P.npar; x += blockDim.x) par[x] = P.par[x];
+    __syncthreads();
+    double *A = core_ptr(P, P.arg, g, p, gs.first);
+    double mx = 0.0;
+    for (int j = tid; j < P.n[p]; j += blockDim.x) {
+        FixIdx ix{P.ind0, p, j + 1};
+        double f = eval_fun<FUN>(P, par, ix);
+        A[(size_t)P.RM * j] = f;
+        mx = fmax(mx, fabs(f));
+    }
+    mx = block_max(mx, shm);
+    if (tid == 0) { atomic_max_pos(&gs.amax, mx); atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)P.n[p]); }
+}
+
+// inv, col, row, index tables of the rank-1 start (:213-217, :235-248)
+__global__ __launch_bounds__(256) void k_init_factors(DevProb P)
+{
+    const int g = blockIdx.y, tid = threadIdx.x;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first, p = first + blockIdx.x, m = P.d;
+    if (p > gs.last + 1) return;
+    const double *A = core_ptr(P, P.arg, g, p, first);
+    if (p <= gs.last) {
+        double piv = A[(size_t)P.RM * (P.ind0[p] - 1)];
+        double rp = 1.0 / piv;
+        double *C = core_ptr(P, P.col, g, p, first);
+        for (int j = tid; j < P.n[p]; j += blockDim.x) C[(size_t)P.RM * j] = rp * A[(size_t)P.RM * j];  // d2_lual, r=1
+        if (tid == 0) {
+            inv_ptr(P, g, p, first)[0] = piv;
+            int *v = vip_ptr(P, g, p, first);
+            v[0] = 1; v[1] = P.ind0[p]; v[2] = P.ind0[p + 1]; v[3] = 1;
+        }
+    }
+    if (p >= first + 1) {
+        double *W = core_ptr(P, P.row, g, p, first);
+        for (int k = tid; k < P.n[p]; k += blockDim.x) W[k] = A[(size_t)P.RM * k];                      // d2_luar, r=1: identity
+    }
+    // tables: L for bonds first-1..last (block b handles bond first-1+b), R for bonds first..last+1
+    {
+        int s = first - 1 + blockIdx.x;                    // L bond
+        short *Lt = L_ptr(P, g, s, first);
+        for (int x = tid; x < s; x += blockDim.x) Lt[(size_t)x * P.RM] = (short)P.ind0[x + 1];
+        int s2 = first + blockIdx.x;                       // R bond
+        short *Rt = R_ptr(P, g, s2, first);
+        for (int x = tid; x < m - s2; x += blockDim.x) Rt[(size_t)x * P.RM] = (short)P.ind0[s2 + 1 + x];
+        if (tid == 0 && blockIdx.x == 0) inv_ptr(P, g, first - 1, first)[0] = 1.0;   // :147
+    }
+}
+
+// pivotmax_prev (:234) and the group's factor of the initial quadrature value (:250-258)
+__global__ void k_init_final(DevProb P)
+{
+    const int g = blockIdx.x;
+    GroupState &gs = P.gs[g];
+    if (threadIdx.x != 0) return;
+    gs.pivotmax_prev = gs.amax;
+    gs.pivotmax = -1.0; gs.pivotmin = -1.0;
+    double val = 1.0;
+    if (P.has_quad) {
+        for (int p = gs.first; p <= gs.last; p++) {
+            const double *A = core_ptr(P, P.arg, g, p, gs.first), *w = P.quadw + (size_t)p * P.NM;
+            double t = 0.0;
+            for (int j = 0; j < P.n[p]; j++) t = t + A[(size_t)P.RM * j] * w[j];
+            val = val * t / inv_ptr(P, g, p, gs.first)[0];
+        }
+        if (gs.last + 1 == P.d && gs.gglobal == P.nprocs - 1) {
+            int p = P.d;
+            const double *A = core_ptr(P, P.arg, g, p, gs.first), *w = P.quadw + (size_t)p * P.NM;
+            double t = 0.0;
+            for (int j = 0; j < P.n[p]; j++) t = t + A[(size_t)P.RM * j] * w[j];
+            val = val * t;
+        }
+    }
+    gs.initval = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_lottery: lottery2 candidates, their values and residuals, start pivot (lib/dmrgg.f90:410-484)
+// one block per group
+// ------------------------------------------------------------------------------------------------
+template <int FUN>
+__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
+{
+    extern __shared__ double dyn[];
+    __shared__ StepState st;
+    __shared__ int zc[128], zr[128], zcs[128], zrs[128], keepc[128], keepr[128];
+    __shared__ int nzc, nzr, nsc, nsr;
+    __shared__ ttx_cdfseg segc[TTX_MAXSEG], segr[TTX_MAXSEG];
+    __shared__ double sha[8], shv[8]; __shared__ int shi[8];
+    const int g = blockIdx.x, tid = threadIdx.x, m = P.d;
+    GroupState &gs = P.gs[g];
+    int *r = P.r + (size_t)g * (m + 2);
+    if (tid == 0) {
+        if (pp == 1) {                                        // sweep start, :325-327
+            gs.pivotmax = -1.0; gs.pivotmin = -1.0;
+            int *rr = P.rr + (size_t)g * (m + 2);
+            for (int s = 0; s <= m; s++) rr[s] = r[s];
+        }
+        int nb = gs.last - gs.first + 1;
+        st.active = (pp <= nb);
+        st.done = 0; st.havecol = 0; st.haverow = 0; st.crs = 0; st.pending = 0; st.pivot = 0.0;
+        st.ii = st.jj = st.kk = st.qq = 0;
+        if (st.active) {
+            int p = (dir == 1) ? gs.first + pp - 1 : gs.last + 1 - pp;   // :330-331
+            st.p = p; st.r0 = r[p - 1]; st.r1 = r[p]; st.r2 = r[p + 1]; st.n1 = P.n[p]; st.n2 = P.n[p + 1];
+        } else { st.p = 0; st.r0 = st.r1 = st.r2 = st.n1 = st.n2 = 0; st.done = 1; }
+    }
+    __syncthreads();
+    if (!st.active) { if (tid == 0) gs.S[0] = st; return; }
+    const int p = st.p, r0 = st.r0, r1 = st.r1, r2 = st.r2, n1 = st.n1, n2 = st.n2, first = gs.first;
+    const int nlot = r0 + n1 + n2 + r2;
+    double *par = dyn, *bval = dyn + P.npar;
+    int *lot = (int *)(bval + nlot);
+    for (int x = tid; x < P.npar; x += blockDim.x) par[x] = P.par[x];
+    // zero-weight positions (existing pivots), :432-439
+    const int *vp = vip_ptr(P, g, p, first);
+    if (tid < r1) {
+        zc[tid] = (vp[4 * tid + 0] - 1) + r0 * (vp[4 * tid + 1] - 1) + 1;
+        zr[tid] = (vp[4 * tid + 2] - 1) + n2 * (vp[4 * tid + 3] - 1) + 1;
+    }
+    __syncthreads();
+    if (tid < r1) {          // rank sort (total order with index tie-break)
+        int a = zc[tid], b = zr[tid], ra = 0, rb = 0;
+        for (int u = 0; u < r1; u++) {
+            ra += (zc[u] < a) || (zc[u] == a && u < tid);
+            rb += (zr[u] < b) || (zr[u] == b && u < tid);
+        }
+        zcs[ra] = a; zrs[rb] = b;
+    }
+    __syncthreads();
+    if (tid < r1) { keepc[tid] = (tid == 0) || (zcs[tid] != zcs[tid - 1]); keepr[tid] = (tid == 0) || (zrs[tid] != zrs[tid - 1]); }
+    __syncthreads();
+    if (tid < r1) {          // compaction of distinct values into zc / zr
+        int pc = 0, pr = 0;
+        for (int u = 0; u < tid; u++) { pc += keepc[u]; pr += keepr[u]; }
+        if (keepc[tid]) zc[pc] = zcs[tid];
+        if (keepr[tid]) zr[pr] = zrs[tid];
+        if (tid == r1 - 1) { nzc = pc + keepc[tid]; nzr = pr + keepr[tid]; }
+    }
+    __syncthreads();
+    const int Kc = r0 * n1 - nzc, Kr = n2 * r2 - nzr;
+    if (tid == 0) nsc = ttx_cdf_build(Kc, segc);
+    if (tid == 64) nsr = ttx_cdf_build(Kr, segr);
+    __syncthreads();
+    const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    double ma = 0.0;
+    double ba = -1.0, bv = 0.0; int bi = INT_MAX;
+    for (int il = tid; il < nlot; il += blockDim.x) {
+        // rnd.f90:120-124: d(nlot,2) column-major from the (never seeded) run-time generator
+        double d1 = ttx_flang_draw(gs.rngpos + il), d2 = ttx_flang_draw(gs.rngpos + nlot + il);
+        int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);
+        int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
+        int j = (x - 1) / r0 + 1, i = (x - 1) % r0 + 1;          // :447-452
+        int q = (y - 1) / n2 + 1, k = (y - 1) % n2 + 1;
+        lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
+        EntryIdx ix{Lt, Rt, P.RM, p, i - 1, j, k, q - 1};
+        double f = eval_fun<FUN>(P, par, ix);                    // :455-463
+        ma = fmax(ma, fabs(f));
+        const double *c = Cp + (i - 1) + (size_t)P.RM * (j - 1), *w = Wq + (k - 1) + (size_t)P.NM * (q - 1);
+        double t = 0.0;                                          // ddot, :474
+        for (int s = 0; s < r1; s++) t = t + c[P.SS * s] * w[P.SW * s];
+        double b = f - t;
+        bval[il] = b;
+        double a = fabs(b);
+        if (a > ba || (a == ba && il < bi)) { ba = a; bv = b; bi = il; }
+    }
+    ma = block_max(ma, sha);
+    block_argmax(ba, bv, bi, sha, shv, shi);
+    if (tid == 0) {
+        gs.amax = fmax(gs.amax, ma);                             // :467
+        gs.neval += nlot;                                        // :465
+        gs.rngpos += 2ull * nlot;
+        st.ii = lot[4 * bi]; st.jj = lot[4 * bi + 1]; st.kk = lot[4 * bi + 2]; st.qq = lot[4 * bi + 3];   // :479-484
+        st.pivot = bv;
+        gs.S[0] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_halfstep: one rook half-step = fiber evaluation (K1) + residual against the cross factor (K2, the
+// "maxvol" kernel of the north star: a bandwidth-bound slab sweep) + block arg-max.
+// lib/dmrgg.f90:518-582 (rook), :492-513 (piv=0).  grid = (fiber blocks, groups).
+// mode 0: rook (type alternates, residual unless crs reached 2*piv); mode 1: piv=0 (h=0 column, h=1 row,
+// no residual).
+// ------------------------------------------------------------------------------------------------
+template <int FUN>
+__global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir, int mode)
+{
+    extern __shared__ double dyn[];
+    __shared__ StepState cur;
+    __shared__ double sha[4], shv[4]; __shared__ int shi[4];
+    const int g = blockIdx.y, tid = threadIdx.x, m = P.d;
+    GroupState &gs = P.gs[g];
+    if (tid == 0) { cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]); }
+    __syncthreads();
+    if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
+    const bool iscol = (mode == 1) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
+    const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
+    const int nf = iscol ? r0 * n1 : n2 * r2;
+    if (blockIdx.x * TTX_BLK >= nf) return;
+    // LDS: par | xs[RM] | fx[d+2] (int) | vt[d*RM] (short)
+    double *par = dyn, *xs = dyn + P.npar;
+    int *fx = (int *)(xs + P.RM);
+    short *vt = (short *)(fx + m + 2);
+    const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    for (int x = tid; x < P.npar; x += TTX_BLK) par[x] = P.par[x];
+    int vrows, vcols;
+    if (iscol) {   // varying: left pivot i (dims 1..p-1) and j; fixed: kk and the right multi-index of qq
+        vrows = p - 1; vcols = r0;
+        for (int x = tid; x < vrows * vcols; x += TTX_BLK) vt[x] = Lt[(size_t)(x / vcols) * P.RM + (x % vcols)];
+        for (int s = p + 1 + tid; s <= m; s += TTX_BLK) fx[s] = (s == p + 1) ? cur.kk : (int)Rt[(size_t)(s - p - 2) * P.RM + (cur.qq - 1)];
+        for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Wq[(cur.kk - 1) + (size_t)P.NM * (cur.qq - 1) + P.SW * s];
+    } else {       // varying: k and right pivot q (dims p+2..m); fixed: left multi-index of ii and jj
+        vrows = m - p - 1; vcols = r2;
+        for (int x = tid; x < vrows * vcols; x += TTX_BLK) vt[x] = Rt[(size_t)(x / vcols) * P.RM + (x % vcols)];
+        for (int s = 1 + tid; s <= p; s += TTX_BLK) fx[s] = (s == p) ? cur.jj : (int)Lt[(size_t)(s - 1) * P.RM + (cur.ii - 1)];
+        for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Cp[(cur.ii - 1) + (size_t)P.RM * (cur.jj - 1) + P.SS * s];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * TTX_BLK + tid;
+    const bool live = t < nf;
+    double a = 0.0;
+    int u = 0, v = 0;                         // col: (i,j) 0-based ; row: (k,q) 0-based
+    if (live) {
+        if (iscol) { u = t % r0; v = t / r0; } else { u = t % n2; v = t / n2; }
+        FiberIdx ix;
+        ix.vt = vt; ix.vstride = vcols; ix.fx = fx;
+        if (iscol) { ix.vcol = u; ix.vfrom = 1; ix.vto = p - 1; ix.self = p; ix.selfval = v + 1; }
+        else       { ix.vcol = v; ix.vfrom = p + 2; ix.vto = m; ix.self = p + 1; ix.selfval = u + 1; }
+        a = eval_fun<FUN>(P, par, ix);                                        // :520-526 / :553-559
+        (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
+    }
+    double mx = block_max(live ? fabs(a) : 0.0, sha);
+    if (tid == 0) atomic_max_pos(&gs.amax, mx);                               // :531 / :564
+    const int crs = cur.crs + 1;
+    const int havecol = cur.havecol | (iscol ? 1 : 0), haverow = cur.haverow | (iscol ? 0 : 1);
+    const int done = (mode == 1) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
+    const bool resid = (mode == 0) && !done;
+    if (resid) {
+        double b = a, ab = -1.0; int bi = INT_MAX;
+        if (live) {
+            if (iscol) {   // dgemv 'n', alpha=-1 (:538): b += (-x_s) * col(:, s)
+                const double *c = Cp + u + (size_t)P.RM * v;
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) b = b + (-xs[s]) * c[P.SS * s];
+            } else {       // dgemv 't', alpha=-1 (:571): b += -1 * sum_s row(s, kq) * x_s
+                const double *w = Wq + u + (size_t)P.NM * v;
+                double tt = 0.0;
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) tt = tt + w[P.SW * s] * xs[s];
+                b = b + (-1.0) * tt;
+            }
+            ab = fabs(b); bi = t;
+        }
+        block_argmax(ab, b, bi, sha, shv, shi);
+        if (tid == 0) { Partial pr; pr.absmax = ab; pr.val = b; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][blockIdx.x] = pr; }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        StepState nx = cur;
+        nx.crs = crs; nx.havecol = havecol; nx.haverow = haverow; nx.done = done;
+        nx.pending = resid ? (iscol ? 1 : 2) : 0;
+        gs.S[h + 1] = nx;
+        gs.neval += nf;                                                       // :527 / :560 / :509
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_accept: threshold test and in-place append of the new cross (lib/dmrgg.f90:598-758).
+// block roles along grid.x: [0,nA) column factor + raw column; [nA,2nA) row factor + raw row;
+// [2nA, 2nA+NM) left-neighbour row fix-up (one column j each); [.., +NM) right-neighbour column fix-up
+// (one row k each); last block: scalars, packed LU, pivot sets and index tables.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TTX_BLK) void k_accept(DevProb P, int H, int nA)
+{
+    extern __shared__ double dyn[];
+    __shared__ StepState cur;
+    __shared__ int s_upd;
+    __shared__ double s_bc;
+    const int g = blockIdx.y, tid = threadIdx.x, m = P.d;
+    GroupState &gs = P.gs[g];
+    if (tid == 0) {
+        cur = gs.S[H]; resolve_state(cur, gs.Pt[(H + 1) & 1]);
+        s_upd = cur.active && (fabs(cur.pivot) > P.small_element * gs.amax) && (fabs(cur.pivot) > P.small_pivot * gs.pivotmax_prev);  // :599-600
+    }
+    __syncthreads();
+    if (!cur.active) return;
+    const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
+    const int bx = blockIdx.x, nblk = gridDim.x;
+    int *tape = P.tape + ((size_t)g * (m + 2) + p) * 4;
+    if (!s_upd) {
+        if (bx == nblk - 1 && tid == 0) { tape[0] = tape[1] = tape[2] = tape[3] = -1; P.upd[(size_t)g * (m + 2) + p] = 0; }
+        return;
+    }
+    const int ii = cur.ii - 1, jj = cur.jj - 1, kk = cur.kk - 1, qq = cur.qq - 1;   // 0-based
+    double *Ap = core_ptr(P, P.arg, g, p, first), *Aq = core_ptr(P, P.arg, g, p + 1, first);
+    double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+    const double *acol = P.acol + (size_t)g * P.RM * P.NM, *arow = P.arow + (size_t)g * P.RM * P.NM;
+    double *xs = dyn;   // RM doubles
+
+    if (bx < nA) {
+        // role A: arg(p)(:,:,r1+1) = acol1 (:662-668); col(p)(:,:,r1+1) = (acol1 - col*Ucol) / pivot (:701, d2_lual from=r1+1)
+        for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Wq[kk + (size_t)P.NM * qq + P.SW * s];
+        __syncthreads();
+        int t = bx * TTX_BLK + tid;
+        if (t < r0 * n1) {
+            int i = t % r0, j = t / r0;
+            size_t o = i + (size_t)P.RM * j;
+            double a = acol[t];
+            Ap[o + P.SS * r1] = a;
+            double y = a;
+            for (int s = 0; s < r1; s++) y = y + (-xs[s]) * Cp[o + P.SS * s];
+            y = (1.0 / cur.pivot) * y;
+            Cp[o + P.SS * r1] = y;
+        }
+    } else if (bx < 2 * nA) {
+        // role B: arg(p+1)(r1+1,:,:) = arow1 (:669-674); row(p+1)(r1+1,:,:) = arow1 - Lrow'*row (:702, d2_luar from=r1+1)
+        for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Cp[ii + (size_t)P.RM * jj + P.SS * s];
+        __syncthreads();
+        int t = (bx - nA) * TTX_BLK + tid;
+        if (t < n2 * r2) {
+            int k = t % n2, q = t / n2;
+            double a = arow[t];
+            Aq[r1 + (size_t)P.RM * k + P.SS * q] = a;
+            size_t o = k + (size_t)P.NM * q;
+            double tt = 0.0;
+            for (int s = 0; s < r1; s++) tt = tt + Wq[o + P.SW * s] * xs[s];
+            Wq[o + P.SW * r1] = a + (-1.0) * tt;
+        }
+    } else if (bx < 2 * nA + P.NM) {
+        // role C: row(p)(:, j, r1+1) = L(p-1)^-1 * acol1(:, j)  (:715-728, d2_luar full) -- wavefront over i
+        int j = bx - 2 * nA;
+        if (p <= first || j >= n1) return;
+        const double *gI = inv_ptr(P, g, p - 1, first);
+        double *Wp = core_ptr(P, P.row, g, p, first);
+        double a = (tid < r0) ? acol[tid + r0 * j] : 0.0, tmp = 0.0, xf = 0.0;
+        for (int s = 0; s < r0; s++) {
+            if (tid == s) { xf = a + (-1.0) * tmp; if (s == 0) xf = a; s_bc = xf; }
+            __syncthreads();
+            if (tid > s && tid < r0) tmp = tmp + s_bc * gI[tid * tid + s];
+            __syncthreads();
+        }
+        if (tid < r0) Wp[j + (size_t)P.NM * r1 + P.SW * tid] = xf;
+    } else if (bx < 2 * nA + 2 * P.NM) {
+        // role D: col(p+1)(r1+1, k, :) = arow1(k, :) * U(p+1)^-1  (:730-749, d2_lual full) -- wavefront over q
+        int k = bx - 2 * nA - P.NM;
+        if (p >= gs.last || k >= n2) return;
+        const double *gI = inv_ptr(P, g, p + 1, first);
+        double *Cq = core_ptr(P, P.col, g, p + 1, first);
+        double y = (tid < r2) ? arow[k + n2 * tid] : 0.0;
+        for (int s = 0; s < r2; s++) {
+            if (tid == s) { y = (1.0 / gI[(s + 1) * (s + 1) - 1]) * y; s_bc = y; }
+            __syncthreads();
+            if (tid > s && tid < r2) y = y + (-gI[tid * tid + tid + s]) * s_bc;
+            __syncthreads();
+        }
+        if (tid < r2) Cq[r1 + (size_t)P.RM * k + P.SS * tid] = y;
+    } else {
+        // role E: scalars (:604-635), packed LU (:649-660), index tables (replaces the vip walk of :1062-1075)
+        double *gI = inv_ptr(P, g, p, first);
+        for (int s = tid; s < r1; s += TTX_BLK) {
+            gI[r1 * r1 + s] = Cp[ii + (size_t)P.RM * jj + P.SS * s];
+            gI[r1 * r1 + r1 + s] = Wq[kk + (size_t)P.NM * qq + P.SW * s];
+        }
+        short *Ln = L_ptr(P, g, p, first), *Rn = R_ptr(P, g, p, first);
+        const short *Lo = L_ptr(P, g, p - 1, first), *Ro = R_ptr(P, g, p + 1, first);
+        for (int x = tid; x < p; x += TTX_BLK) Ln[(size_t)x * P.RM + r1] = (x < p - 1) ? Lo[(size_t)x * P.RM + ii] : (short)(jj + 1);
+        for (int x = tid; x < m - p; x += TTX_BLK) Rn[(size_t)x * P.RM + r1] = (x == 0) ? (short)(kk + 1) : Ro[(size_t)(x - 1) * P.RM + qq];
+        if (tid == 0) {
+            gI[(r1 + 1) * (r1 + 1) - 1] = cur.pivot;
+            int *vp = vip_ptr(P, g, p, first) + 4 * r1;
+            vp[0] = tape[0] = ii + 1; vp[1] = tape[1] = jj + 1; vp[2] = tape[2] = kk + 1; vp[3] = tape[3] = qq + 1;
+            double ap = fabs(cur.pivot);
+            gs.pivotmax = (gs.pivotmax < 0.0) ? ap : fmax(gs.pivotmax, ap);
+            gs.pivotmin = (gs.pivotmin < 0.0) ? ap : fmin(gs.pivotmin, ap);
+            P.upd[(size_t)g * (m + 2) + p] = 1;
+            P.r[(size_t)g * (m + 2) + p] = r1 + 1;                                      // :752
+        }
+    }
+}
+
+// per-sweep bookkeeping for a single group (:961); the multi-group exchange kernels set it themselves
+__global__ void k_sweep_end(DevProb P)
+{
+    GroupState &gs = P.gs[blockIdx.x];
+    if (threadIdx.x == 0) gs.pivotmax_prev = gs.pivotmax;
+}
+
+// ------------------------------------------------------------------------------------------------
+// quadrature (lib/dmrgg.f90:975-993 per sweep, :1261-1415 dtt_quad) and finalisation dtt_lua (:1169-1258)
+// ------------------------------------------------------------------------------------------------
+// mode 0: T = sum_j w_j arg(:,j,:) on raw fibers, then L(p-1)^-1 T U(p)^-1 (ttqq + dtt_lua);
+// mode 1: T = sum_j w_j arg(:,j,:) on finalised cores (w == NULL: plain sum)
+__global__ __launch_bounds__(256) void k_quad_build(DevProb P, int mode, const double *wq)
+{
+    extern __shared__ double T[];   // RM*RM
+    const int g = blockIdx.y, tid = threadIdx.x, RM = P.RM;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first, p = first + blockIdx.x;
+    const bool lastgroup = (gs.gglobal == P.nprocs - 1);
+    if (p > gs.last && !(lastgroup && p == P.d)) return;
+    const int *r = P.r + (size_t)g * (P.d + 2);
+    const int r0 = r[p - 1], r1 = r[p], n = P.n[p];
+    const double *A = core_ptr(P, P.arg, g, p, first);
+    const double *w = wq ? wq + (size_t)p * P.NM : nullptr;
+    for (int x = tid; x < r0 * r1; x += blockDim.x) {
+        int i = x % r0, k = x / r0;
+        const double *a = A + i + P.SS * k;
+        double y = 0.0;
+        if (w) for (int j = 0; j < n; j++) y = y + w[j] * a[(size_t)RM * j];     // dgemv 'n', :988 / :1327
+        else   for (int j = 0; j < n; j++) y = y + a[(size_t)RM * j];            // :1331
+        T[i + RM * k] = y;
+    }
+    __syncthreads();
+    if (mode == 0) {
+        const double *gL = inv_ptr(P, g, p - 1, first);
+        if (tid < r1) {                               // d2_luar(n*r1 -> r1 columns, r0, inv(p-1)) :1250
+            double *c = T + RM * tid;
+            for (int t = 1; t < r0; t++) {
+                double tmp = 0.0;
+                for (int s = 0; s < t; s++) tmp = tmp + c[s] * gL[t * t + s];
+                c[t] = c[t] + (-1.0) * tmp;
+            }
+        }
+        __syncthreads();
+        if (p <= gs.last && tid < r0) {               // d2_lual(r0 rows, r1, inv(p)) :1251
+            const double *gU = inv_ptr(P, g, p, first);
+            for (int t = 0; t < r1; t++) {
+                double y = T[tid + RM * t];
+                for (int s = 0; s < t; s++) y = y + (-gU[t * t + t + s]) * T[tid + RM * s];
+                T[tid + RM * t] = (1.0 / gU[(t + 1) * (t + 1) - 1]) * y;
+            }
+        }
+        __syncthreads();
+    }
+    double *out = P.Tq + ((size_t)g * P.NC + (p - first)) * (size_t)RM * RM;
+    for (int x = tid; x < r0 * r1; x += blockDim.x) out[(x % r0) + RM * (x / r0)] = T[(x % r0) + RM * (x / r0)];
+}
+
+// chain product of the group's T matrices (dgemm 'n','n' order, :1340); one block per group
+__global__ __launch_bounds__(256) void k_quad_chain(DevProb P)
+{
+    extern __shared__ double sh[];  // 2*RM*RM
+    const int g = blockIdx.x, tid = threadIdx.x, RM = P.RM;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first;
+    const bool lastgroup = (gs.gglobal == P.nprocs - 1);
+    const int lastc = lastgroup ? P.d : gs.last;
+    const int *r = P.r + (size_t)g * (P.d + 2);
+    const int mym = r[first - 1];
+    double *prev = sh, *next = sh + RM * RM;
+    const double *T0 = P.Tq + ((size_t)g * P.NC) * (size_t)RM * RM;
+    for (int x = tid; x < mym * r[first]; x += blockDim.x) prev[(x % mym) + RM * (x / mym)] = T0[(x % mym) + RM * (x / mym)];
+    __syncthreads();
+    for (int p = first + 1; p <= lastc; p++) {
+        const double *Tc = P.Tq + ((size_t)g * P.NC + (p - first)) * (size_t)RM * RM;
+        const int r0 = r[p - 1], r1 = r[p];
+        for (int x = tid; x < mym * r1; x += blockDim.x) {
+            int i = x % mym, j = x / mym;
+            double c = 0.0;
+            for (int l = 0; l < r0; l++) c = c + Tc[l + RM * j] * prev[i + RM * l];
+            next[i + RM * j] = c;
+        }
+        __syncthreads();
+        double *t = prev; prev = next; next = t;
+    }
+    const int myn = r[lastc];
+    double *out = P.qpart + (size_t)g * RM * RM;
+    for (int x = tid; x < mym * myn; x += blockDim.x) out[(x % mym) + RM * (x / mym)] = prev[(x % mym) + RM * (x / mym)];
+    if (P.nprocs == 1 && tid == 0) gs.val = prev[0];
+}
+
+// dtt_lua on the raw fibers: luar pass then lual pass (two launches: the second needs the whole core)
+__global__ __launch_bounds__(256) void k_fin_luar(DevProb P)
+{
+    const int g = blockIdx.y, RM = P.RM;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first, p = first + blockIdx.x;
+    const bool lastgroup = (gs.gglobal == P.nprocs - 1);
+    if (p > gs.last && !(lastgroup && p == P.d)) return;
+    const int *r = P.r + (size_t)g * (P.d + 2);
+    const int r0 = r[p - 1], r1 = r[p], n = P.n[p];
+    double *A = core_ptr(P, P.arg, g, p, first);
+    const double *gL = inv_ptr(P, g, p - 1, first);
+    for (int x = threadIdx.x; x < n * r1; x += blockDim.x) {       // one column (j,k) per thread, :1250
+        double *c = A + (size_t)RM * (x % n) + P.SS * (x / n);
+        for (int t = 1; t < r0; t++) {
+            double tmp = 0.0;
+            for (int s = 0; s < t; s++) tmp = tmp + c[s] * gL[t * t + s];
+            c[t] = c[t] + (-1.0) * tmp;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_fin_lual(DevProb P)
+{
+    const int g = blockIdx.y, RM = P.RM;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first, p = first + blockIdx.x;
+    if (p > gs.last) return;
+    const int *r = P.r + (size_t)g * (P.d + 2);
+    const int r0 = r[p - 1], r1 = r[p], n = P.n[p];
+    double *A = core_ptr(P, P.arg, g, p, first);
+    const double *gU = inv_ptr(P, g, p, first);
+    for (int x = threadIdx.x; x < r0 * n; x += blockDim.x) {       // one row (i,j) per thread, :1251
+        double *c = A + (x % r0) + (size_t)RM * (x / r0);
+        for (int t = 0; t < r1; t++) {
+            double y = c[P.SS * t];
+            for (int s = 0; s < t; s++) y = y + (-gU[t * t + t + s]) * c[P.SS * s];
+            c[P.SS * t] = (1.0 / gU[(t + 1) * (t + 1) - 1]) * y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone kernels behind the ttx_k_* test entry points (same device functions as the sweep)
+// ------------------------------------------------------------------------------------------------
+struct ListIdx { const int *ind; __device__ __forceinline__ int operator()(int s) const { return ind[s - 1]; } };
+template <int FUN>
+__global__ void k_eval_list(DevProb P, long long npts, const int *ind, double *out)
+{
+    extern __shared__ double dyn[];
+    for (int x = threadIdx.x; x < P.npar; x += blockDim.x) dyn[x] = P.par[x];
+    __syncthreads();
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npts) return;
+    ListIdx ix{ind + t * P.d};
+    out[t] = eval_fun<FUN>(P, dyn, ix);
+}
+
+// b = a - F x (dgemv 'n' order) + per-block first arg-max; F is m x r with leading dimension ld
+__global__ __launch_bounds__(TTX_BLK) void k_resid_argmax(int m, int r, size_t ld, const double *a, const double *F, const double *x,
+                                                          double *b_out, Partial *parts)
+{
+    __shared__ double xs[256];
+    __shared__ double sha[4], shv[4]; __shared__ int shi[4];
+    for (int s = threadIdx.x; s < r; s += TTX_BLK) xs[s] = x[s];
+    __syncthreads();
+    int t = blockIdx.x * TTX_BLK + threadIdx.x;
+    double b = 0.0, ab = -1.0; int bi = INT_MAX;
+    if (t < m) {
+        b = a[t];
+#pragma unroll 8
+        for (int s = 0; s < r; s++) b = b + (-xs[s]) * F[t + ld * s];
+        b_out[t] = b; ab = fabs(b); bi = t;
+    }
+    block_argmax(ab, b, bi, sha, shv, shi);
+    if (threadIdx.x == 0) { Partial pr; pr.absmax = ab; pr.val = b; pr.idx = bi; pr.pad = 0; parts[blockIdx.x] = pr; }
+}
+
+__global__ void k_lottery_only(int npnt, int m, int n, int nz, const int *zcol, const int *zrow, unsigned long long rngpos, int *points)
+{
+    __shared__ ttx_cdfseg segc[TTX_MAXSEG], segr[TTX_MAXSEG];
+    __shared__ int nsc, nsr;
+    if (threadIdx.x == 0) nsc = ttx_cdf_build(m - nz, segc);
+    if (threadIdx.x == 64) nsr = ttx_cdf_build(n - nz, segr);
+    __syncthreads();
+    for (int il = threadIdx.x; il < npnt; il += blockDim.x) {
+        double d1 = ttx_flang_draw(rngpos + il), d2 = ttx_flang_draw(rngpos + npnt + il);
+        points[il] = ttx_lottery_index(segc, nsc, m - nz, m, zcol, nz, d1);
+        points[npnt + il] = ttx_lottery_index(segr, nsr, n - nz, n, zrow, nz, d2);
+    }
+}

@@ -1,0 +1,244 @@
+"""ctypes binding of libttx.so (include/ttx.h) and a host-side mirror of the reference's dmrgg_lib API.
+
+Reference interface mirrored (lib/dmrgg.f90:11-26):
+    subroutine dtt_dmrgg(arg, fun, par, accuracy, maxrank, mybonds, pivoting, neval, quad, tru)
+    double precision function dtt_quad(arg, quad, mybonds)
+`fun` is replaced by the id of a built-in device integrand (TTX_FUN_*), everything else keeps its name,
+meaning and error behaviour (the reference prints and stops; here TTXError carries the same message).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_uint8, c_uint64, c_void_p
+
+import numpy as np
+
+TTX_FUN_ISING, TTX_FUN_STDNORM, TTX_FUN_MVN = 1, 2, 3
+K_NAMES = ("lottery", "halfstep", "accept", "exchange", "quad", "other")
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libttx.so")
+
+
+class TTXError(RuntimeError):
+    pass
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [("d", c_int32), ("n", POINTER(c_int32)), ("fun_id", c_int32), ("par", POINTER(c_double)),
+                ("npar", c_int32), ("aux", POINTER(c_double)), ("naux", c_int32), ("quadw", POINTER(c_double)),
+                ("accuracy", c_double), ("maxrank", c_int32), ("pivoting", c_int32), ("tru", c_double),
+                ("has_tru", c_int32), ("nproc", c_int32), ("mybonds", POINTER(c_int32)), ("device", c_int32),
+                ("world_rank", c_int32), ("world_size", c_int32), ("verbose", c_int32), ("use_graph", c_int32)]
+
+
+class SweepRec(ctypes.Structure):
+    _fields_ = [("it", c_int32), ("dir", c_int32), ("erank", c_double), ("neval", c_int64), ("val", c_double),
+                ("amax", c_double), ("pivotmax", c_double), ("pivotmin", c_double), ("seconds", c_double)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libttx.so; fails loudly if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise TTXError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the engine has no CPU path)")
+    L = ctypes.CDLL(p)
+    L.ttx_last_error.restype = c_char_p
+    L.ttx_version.restype = ctypes.c_int
+    L.ttx_create.argtypes = [POINTER(c_void_p), POINTER(_Config)]
+    L.ttx_destroy.argtypes = [c_void_p]
+    L.ttx_destroy.restype = None
+    L.ttx_comm_unique_id.argtypes = [POINTER(c_uint8)]
+    L.ttx_comm_init.argtypes = [c_void_p, POINTER(c_uint8)]
+    L.ttx_run.argtypes = [c_void_p]
+    L.ttx_num_sweeps.argtypes = [c_void_p]
+    L.ttx_get_sweeps.argtypes = [c_void_p, POINTER(SweepRec), ctypes.c_int]
+    L.ttx_get_tapes.argtypes = [c_void_p, POINTER(c_int32), c_int64]
+    L.ttx_neval.argtypes = [c_void_p]
+    L.ttx_neval.restype = c_int64
+    L.ttx_seconds.argtypes = [c_void_p]
+    L.ttx_seconds.restype = c_double
+    L.ttx_get_ranks.argtypes = [c_void_p, POINTER(c_int32)]
+    L.ttx_core_size.argtypes = [c_void_p, ctypes.c_int]
+    L.ttx_core_size.restype = c_int64
+    L.ttx_get_core.argtypes = [c_void_p, ctypes.c_int, POINTER(c_double)]
+    L.ttx_quad.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
+    L.ttx_set_profile.argtypes = [c_void_p, ctypes.c_int]
+    L.ttx_kernel_stats.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
+    L.ttx_k_residual_argmax.argtypes = [c_int32, c_int32, c_int32, POINTER(c_double), POINTER(c_double),
+                                        POINTER(c_double), POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
+    L.ttx_k_eval.argtypes = [c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_double), c_int32,
+                             POINTER(c_double), c_int32, c_int64, POINTER(c_int32), POINTER(c_double)]
+    L.ttx_k_lottery.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),
+                                c_uint64, POINTER(c_int32)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise TTXError(load_library().ttx_last_error().decode())
+
+
+def _dp(a):
+    return a.ctypes.data_as(POINTER(c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(POINTER(c_int32)) if a is not None else None
+
+
+class TTCross:
+    """One dtt_dmrgg problem resident on one MI355X (the `type(dtt) :: arg` of the reference plus the
+    sweep state).  n: mode sizes arg%n(1:d); quad: list/array of per-mode weight vectors (rank-1 TT)."""
+
+    def __init__(self, n, fun_id, par, maxrank, pivoting=3, accuracy=None, quad=None, tru=None, aux=None,
+                 nproc=1, mybonds=None, device=0, verbose=False, use_graph=False):
+        L = load_library()
+        self._n = np.ascontiguousarray(n, dtype=np.int32)
+        self.d = int(self._n.size)
+        self._par = np.ascontiguousarray(par, dtype=np.float64)
+        self._aux = None if aux is None else np.ascontiguousarray(aux, dtype=np.float64)
+        self._quad = None if quad is None else np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.float64).ravel() for q in quad]))
+        self._mybonds = None if mybonds is None else np.ascontiguousarray(mybonds, dtype=np.int32)
+        c = _Config()
+        c.d = self.d
+        c.n = _ip(self._n)
+        c.fun_id = fun_id
+        c.par = _dp(self._par)
+        c.npar = self._par.size
+        c.aux = _dp(self._aux)
+        c.naux = 0 if self._aux is None else self._aux.size
+        c.quadw = _dp(self._quad)
+        c.accuracy = -1.0 if accuracy is None else float(accuracy)
+        c.maxrank = int(maxrank)
+        c.pivoting = int(pivoting)
+        c.tru = 0.0 if tru is None else float(tru)
+        c.has_tru = 0 if tru is None else 1
+        c.nproc = int(nproc)
+        c.mybonds = _ip(self._mybonds)
+        c.device = int(device)
+        c.world_rank, c.world_size = 0, 1
+        c.verbose = 1 if verbose else 0
+        c.use_graph = 1 if use_graph else 0
+        self._h = c_void_p()
+        _check(L.ttx_create(ctypes.byref(self._h), ctypes.byref(c)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().ttx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_profile(self, on=True):
+        _check(load_library().ttx_set_profile(self._h, 1 if on else 0))
+
+    def run(self):
+        _check(load_library().ttx_run(self._h))
+        return self
+
+    # ---- results -----------------------------------------------------------------------------
+    @property
+    def neval(self):
+        return int(load_library().ttx_neval(self._h))
+
+    @property
+    def seconds(self):
+        return float(load_library().ttx_seconds(self._h))
+
+    def sweeps(self):
+        L = load_library()
+        k = L.ttx_num_sweeps(self._h)
+        buf = (SweepRec * k)()
+        _check(L.ttx_get_sweeps(self._h, buf, k))
+        return [dict(it=b.it, dir=b.dir, erank=b.erank, neval=b.neval, val=b.val, amax=b.amax,
+                     pivotmax=b.pivotmax, pivotmin=b.pivotmin, seconds=b.seconds) for b in buf]
+
+    def tapes(self):
+        L = load_library()
+        k = L.ttx_num_sweeps(self._h) - 1
+        out = np.zeros((max(k, 0), self.d + 1, 4), dtype=np.int32)
+        if k > 0:
+            _check(L.ttx_get_tapes(self._h, _ip(out), out.size))
+        return out
+
+    def ranks(self):
+        r = np.zeros(self.d + 1, dtype=np.int32)
+        _check(load_library().ttx_get_ranks(self._h, _ip(r)))
+        return r
+
+    def core(self, k):
+        """arg%u(k)%p as a Fortran-ordered (r(k-1), n(k), r(k)) array, k = 1..d."""
+        L = load_library()
+        r = self.ranks()
+        sz = L.ttx_core_size(self._h, k)
+        buf = np.zeros(sz, dtype=np.float64)
+        _check(L.ttx_get_core(self._h, k, _dp(buf)))
+        return buf.reshape((r[k - 1], self._n[k - 1], r[k]), order="F")
+
+    def quad(self, w=None):
+        """dtt_quad(arg, quad) (lib/dmrgg.f90:1261); w = list of per-mode weight vectors or None."""
+        v = c_double()
+        wa = None if w is None else np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.float64).ravel() for q in w]))
+        _check(load_library().ttx_quad(self._h, _dp(wa), ctypes.byref(v)))
+        return v.value
+
+    def kernel_stats(self):
+        n = (c_int64 * 6)()
+        ms = (c_double * 6)()
+        by = (c_double * 6)()
+        _check(load_library().ttx_kernel_stats(self._h, n, ms, by))
+        return {K_NAMES[i]: dict(launches=int(n[i]), ms=float(ms[i]), bytes=float(by[i])) for i in range(6)}
+
+
+def dtt_dmrgg(n, fun_id, par, accuracy=None, maxrank=None, mybonds=None, pivoting=3, quad=None, tru=None, aux=None,
+              nproc=1, device=0, verbose=False):
+    """Mirror of `call dtt_dmrgg(arg, fun, par, accuracy, maxrank, mybonds, pivoting, neval, quad, tru)`;
+    returns the engine (holding the finalised cores, ranks, neval and per-sweep records)."""
+    if maxrank is None:
+        raise TTXError("dtt_dmrgg: maxrank is required by the device engine (it sizes HBM storage)")
+    return TTCross(n, fun_id, par, maxrank, pivoting=pivoting, accuracy=accuracy, quad=quad, tru=tru, aux=aux,
+                   nproc=nproc, mybonds=mybonds, device=device, verbose=verbose).run()
+
+
+# ---- kernel-level entry points (parity tests) --------------------------------------------------------
+def k_residual_argmax(a, F, x, device=0):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    F = np.asfortranarray(F, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    m, r = F.shape
+    b = np.zeros(m)
+    im = c_int32()
+    bm = c_double()
+    _check(load_library().ttx_k_residual_argmax(device, m, r, _dp(a), F.ctypes.data_as(POINTER(c_double)), _dp(x), _dp(b),
+                                                ctypes.byref(im), ctypes.byref(bm)))
+    return b, im.value, bm.value
+
+
+def k_eval(fun_id, n, par, ind, aux=None, device=0):
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    ind = np.ascontiguousarray(ind, dtype=np.int32)
+    aux_ = None if aux is None else np.ascontiguousarray(aux, dtype=np.float64)
+    out = np.zeros(ind.shape[0])
+    _check(load_library().ttx_k_eval(device, fun_id, n.size, _ip(n), _dp(par), par.size, _dp(aux_), 0 if aux_ is None else aux_.size,
+                                     ind.shape[0], _ip(ind), _dp(out)))
+    return out
+
+
+def k_lottery(npnt, m, n, zcol, zrow, rngpos=0, device=0):
+    zc = np.ascontiguousarray(zcol, dtype=np.int32)
+    zr = np.ascontiguousarray(zrow, dtype=np.int32)
+    pts = np.zeros(2 * npnt, dtype=np.int32)
+    _check(load_library().ttx_k_lottery(device, npnt, m, n, zc.size, _ip(zc), _ip(zr), rngpos, _ip(pts)))
+    return pts.reshape(2, npnt)
