@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- fiber evaluations per second of the dtt_dmrgg greedy-cross sweep on MI355X.
+
+A "step" is one complete dtt_dmrgg run (initial cross, all sweeps to the reference's stop rule, finalisation)
+on the workload BASELINE.json's metric is quoted on: Ising C_64, n=51, maxrank 32, pivoting 2 (63 cores).
+`value` = neval / wall(dtt_dmrgg), the reference's own figure of merit (test_crs_ising.f90:146-156), with all
+inputs resident in HBM.  For N>1 the SAME problem is split over N GPUs by bond groups (strong scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c64|c16|d32]
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (the rook half-step:
+fiber evaluation + residual + arg-max), `cpu_baseline` = the genuine reference (oracle/_ref, kind
+"reference") or the C oracle (kind "port") timed on the host cores on the same workload.
+"""
+import argparse
+import json
+import os
+import re
+import statistics
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (driver argv, description)
+    "c64": (("ising", "c", 64, 51, 32, 2), "Ising C_64 n=51 r=32 piv=2 (d=63)"),
+    "c16": (("ising", "c", 16, 51, 32, 2), "Ising C_16 n=51 r=32 piv=2 (d=15)"),
+    "d32": (("ising", "d", 32, 51, 24, 2), "Ising D_32 n=51 r=24 piv=2 (d=31)"),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(argv, budget_s=15.0):
+    """Time the CPU path on the same workload: the genuine reference if oracle/_ref was built and runs here,
+    else the C oracle (single thread).  Bounded sample: repeated full runs for ~budget_s."""
+    kind, m, n, r, piv = argv[1].upper(), argv[2], argv[3], argv[4], argv[5]
+    cores = os.cpu_count() or 1
+    exe = os.path.join(ROOT, "oracle", "_ref", "test_crs_ising")
+    runs = []
+    if os.path.exists(exe):
+        # the reference's OpenMP regions are tiny (a fiber of <= r*n evaluations): more threads than ~8 only add
+        # fork/join cost, so the best of {8, 1} threads is reported (thread count stated in `cores`)
+        best = None
+        for thr in sorted({min(cores, 8), 1}, reverse=True):
+            env = dict(os.environ, OMP_NUM_THREADS=str(thr), MKL_THREADING_LAYER="SEQUENTIAL", OMP_PROC_BIND="close")
+            runs = []
+            t0 = time.time()
+            try:
+                while time.time() - t0 < budget_s / 2 and len(runs) < 15:
+                    out = subprocess.run([exe, kind, str(m), str(n), str(r), str(piv)], capture_output=True, text=True, env=env, timeout=300).stdout
+                    mm = re.search(r"\.\.\.with\s+(\d+) evaluations completed in\s+([0-9.E+-]+) sec", out)
+                    if not mm:
+                        runs = []
+                        break
+                    runs.append((int(mm.group(1)), float(mm.group(2))))
+            except Exception:
+                runs = []
+            if runs:
+                rate = statistics.median([a / b for a, b in runs])
+                if best is None or rate > best[0]:
+                    best = (rate, thr, len(runs), statistics.median([b for _, b in runs]))
+        if best:
+            return {"value": best[0], "unit": "evals/s", "cores": best[1], "kind": "reference",
+                    "sample": f"{best[2]} full runs of test_crs_ising {kind} {m} {n} {r} {piv} (genuine reference, amdflang -O2 -fopenmp + MKL sequential, "
+                              f"OMP_NUM_THREADS={best[1]} of {cores} host cores); median neval/internal time; median time {best[3]:.4f} s"}
+        runs = []
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from ttcross_amd import drivers as D
+    s = D.ising_setup(argv[1], m, n)
+    t0 = time.time()
+    while time.time() - t0 < budget_s and len(runs) < 25:
+        o = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"])
+        runs.append((o["neval"], o["seconds"]))
+    rates = [a / b for a, b in runs]
+    return {"value": statistics.median(rates), "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{len(runs)} full runs of the C oracle (oracle/ttx_oracle.c, 1 thread) on the same workload"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c64", choices=sorted(WORKLOADS))
+    ap.add_argument("--groups", type=int, default=0, help="bond groups (virtual MPI ranks of the reference); default = gpus")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from ttcross_amd import drivers as D
+    from ttcross_amd import engine as E
+
+    argv, desc = WORKLOADS[a.workload]
+    s = D.ising_setup(argv[1], argv[2], argv[3])
+    groups = a.groups or world
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
+                   nproc=groups, device=local, world_rank=rank, world_size=world) if world > 1 else \
+        E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
+                  nproc=groups, device=local)
+    if world > 1:
+        tt.comm_init(dist)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tt.run()
+    barrier()
+    t0 = time.perf_counter()
+    neval = 0
+    for _ in range(a.steps):
+        tt.run()            # ends with a stream synchronisation: all device work of the step is complete
+        neval += tt.neval
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = tt.quad(s["quad"])
+    nsweeps = len(tt.sweeps()) - 1
+
+    # roofline pass: the same step with every launch bracketed by HIP events on the engine's stream
+    tt.set_profile(True)
+    agg = {}
+    for _ in range(max(1, min(a.steps, 3))):
+        tt.run()
+        for k, v in tt.kernel_stats().items():
+            g = agg.setdefault(k, dict(launches=0, ms=0.0, bytes=0.0))
+            for f in g:
+                g[f] += v[f]
+    tt.set_profile(False)
+    hs = agg["halfstep"]
+    avg_us = 1e3 * hs["ms"] / max(hs["launches"], 1)
+    bytes_per_launch = hs["bytes"] / max(hs["launches"], 1)
+    achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+
+    if rank != 0:
+        return
+    out = {
+        "metric": "fiber evals/s (neval / wall time of dtt_dmrgg), " + desc,
+        "value": neval / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic (integrand evaluated on the fly; Gauss-Legendre nodes/weights; flang-compatible lottery RNG stream)",
+        "config": {"workload": desc, "driver": "test_crs_ising " + " ".join(str(x) for x in argv[1:]), "bond_groups": groups,
+                   "neval_per_step": neval // a.steps, "sweeps": nsweeps, "integral": value,
+                   "rel_err_vs_analytic": abs(1 - value / s["tru"]) if s["tru"] else None},
+        "roofline": {"kernel": "k_halfstep (fiber evaluation + residual + arg-max)", "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_us": avg_us, "launches_per_step": hs["launches"] / max(1, min(a.steps, 3)),
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
+        "kernel_ms_per_step": {k: v["ms"] / max(1, min(a.steps, 3)) for k, v in agg.items()},
+    }
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(argv)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,30 @@ def test_ising_sweep_bit_exact(kind, m, n, r, piv):
         assert abs(1 - tt.quad(s["quad"]) / s["tru"]) < (1e-12 if r >= 32 else 1e-6)
 
 
+GROUP_CASES = [("c", 6, 33, 20, 2, 2), ("c", 6, 33, 20, 2, 4), ("d", 8, 33, 10, 2, 3), ("c", 16, 51, 32, 2, 8), ("c", 64, 51, 32, 2, 8),
+               ("c", 64, 51, 32, 2, 5), ("e", 9, 33, 12, 3, 7)]
+
+
+@pytest.mark.parametrize("kind,m,n,r,piv,nproc", GROUP_CASES, ids=[f"{c[0]}{c[1]}_r{c[3]}_p{c[4]}_np{c[5]}" for c in GROUP_CASES])
+def test_bond_groups_bit_exact(kind, m, n, r, piv, nproc):
+    """nproc bond groups on one GPU == the reference's nproc MPI ranks (oracle virtual ranks): tape, boundary
+    exchange both ways, corner evaluations, lagged erank, inv shift and the quadrature tree."""
+    s = D.ising_setup(kind, m, n)
+    tt, oo = _run_both(s, r, piv, nproc=nproc)
+    gs, os_ = tt.sweeps(), oo["sweeps"]
+    assert len(gs) == len(os_)
+    assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d]), "pivot tapes differ"
+    for a, b in zip(gs, os_):
+        assert a["neval"] == b["neval"], f"sweep {a['it']}: neval {a['neval']} vs {b['neval']}"
+        assert a["erank"] == b["erank"]
+        assert a["val"] == b["val"], f"sweep {a['it']}: val {a['val']!r} vs {b['val']!r}"
+        assert a["amax"] == b["amax"] and a["pivotmax"] == b["pivotmax"]
+    assert np.array_equal(tt.ranks(), oo["r"])
+    for k in range(1, tt.d + 1):
+        assert np.array_equal(tt.core(k), oo["cores"][k - 1]), f"core {k} differs"
+    assert tt.quad(s["quad"]) == oo["value"]
+
+
 @pytest.mark.parametrize("kind,d,n,r,piv", [("stdnorm", 4, 33, 10, 2), ("mvn", 6, 33, 12, 2)])
 def test_exp_integrands(kind, d, n, r, piv):
     s = D.box_setup(kind, d, n)

@@ -89,27 +89,27 @@ TTX_HD int ttx_cdf_build(int K, ttx_cdfseg *seg)
     return ns;
 }
 
-// largest k in [0, K] with a_k <= y
+// largest k in [0, K] with a_k <= y  (binary search over the segments, then exact integer arithmetic)
 TTX_HD int ttx_cdf_kmax(const ttx_cdfseg *seg, int ns, double y)
 {
-    int kbest = 0;
-    for (int s = 0; s < ns; s++) {
-        if (!(seg[s].a0 <= y)) break;
-        if (seg[s].cnt == 1 || y >= seg[s].alast) { kbest = seg[s].k0 + seg[s].cnt - 1; continue; }
-        int be = ttx_bexp(seg[s].a0);
-        int64_t A = ttx_units(y, be) - ttx_units(seg[s].a0, be);  // y in [a0, alast): same binade, exact
-        int64_t D = ttx_units(seg[s].delta, be);
-        kbest = seg[s].k0 + (int)(A / D);
-    }
-    return kbest;
+    int lo = -1, hi = ns;                         // last segment with a0 <= y
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (seg[mid].a0 <= y) lo = mid; else hi = mid; }
+    if (lo < 0) return 0;
+    const ttx_cdfseg sg = seg[lo];
+    if (sg.cnt == 1 || y >= sg.alast) return sg.k0 + sg.cnt - 1;
+    int be = ttx_bexp(sg.a0);
+    int64_t A = ttx_units(y, be) - ttx_units(sg.a0, be);   // y in [a0, alast): same binade, exact
+    int64_t D = ttx_units(sg.delta, be);
+    return sg.k0 + (int)(A / D);
 }
 
-// 1-based position of the kth (1-based) non-zero weight, given the ascending distinct 1-based zero positions
+// 1-based position of the kth (1-based) non-zero weight, given the ascending distinct 1-based zero positions:
+// kth + #{t : zeros[t] - t <= kth} (zeros[t] - t is non-decreasing, so the count is a binary search)
 TTX_HD int ttx_select_nonzero(int kth, const int32_t *zeros, int nz)
 {
-    int x = kth;
-    for (int t = 0; t < nz; t++) if (zeros[t] <= x) x++;
-    return x;
+    int lo = 0, hi = nz;                          // first t with zeros[t] - t > kth
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (zeros[mid] - mid <= kth) lo = mid + 1; else hi = mid; }
+    return kth + lo;
 }
 
 // lottery index (1-based in 1..m) for uniform draw y: lib/rnd.f90:122-123 incl. the clamp to m
@@ -121,7 +121,13 @@ TTX_HD int ttx_lottery_index(const ttx_cdfseg *seg, int ns, int K, int m, const 
 }
 
 // flang run-time random_number (unseeded): minstd 48271 mod 2^31-1 from seed 1, two words per double
-TTX_HD uint64_t ttx_mulmod31(uint64_t a, uint64_t b) { return (a * b) % 2147483647ULL; }
+TTX_HD uint64_t ttx_mulmod31(uint64_t a, uint64_t b)
+{   // (a*b) mod (2^31-1) for a,b < 2^31, by Mersenne folding (no 64-bit division on the device)
+    uint64_t x = a * b;
+    x = (x & 2147483647ULL) + (x >> 31);
+    x = (x & 2147483647ULL) + (x >> 31);
+    return (x >= 2147483647ULL) ? x - 2147483647ULL : x;
+}
 TTX_HD double ttx_flang_draw(uint64_t k)
 {
     uint64_t e = 2 * k + 1, base = 48271ULL, w1 = 1;

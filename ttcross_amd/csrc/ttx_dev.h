@@ -47,6 +47,8 @@ struct GroupState {
     unsigned long long rngpos;
     double val;            // per-sweep quadrature value (group 0)
     double initval;        // initial-cross value factor of this group
+    double bytes_half;     // algorithmic bytes moved by the half-step kernel, for the roofline
+    long long n_resid;     // half-steps that computed a residual
     StepState S[TTX_MAXH];
     Partial Pt[2][TTX_MAXPART];
 };
@@ -72,5 +74,17 @@ struct DevProb {
     double *Tq;                // [G][NC][RM*RM]
     double *qpart;             // [G][RM*RM]
     int *ind0;                 // [d+2] initial cross index
+    // per-sweep neighbour exchange (lib/dmrgg.f90:763-958 + lib/dmrggmp.f90:572-629).  Each group packs one
+    // message for its right and one for its left neighbour; in* point at the message to consume: the
+    // neighbour's send buffer when it lives on this GPU, an RCCL receive buffer otherwise.
+    int *sendR_h, *sendL_h;        // [G][XH]      header: upd, tape(4), new rank
+    int *sendR_i, *sendL_i;        // [G][d+2]     full multi-index of the new boundary pivot
+    double *sendR_d, *sendL_d;     // [G][XD]      boundary fiber (+ inv for the right-going message)
+    int **inL_h, **inR_h, **inL_i, **inR_i;   // [G] message from the left / right neighbour (nullptr: none)
+    double **inL_d, **inR_d;
+    double *red;                   // [G][4] amax, pivotmax, -pivotmin (for the MAX all-reduce, :852-870)
+    size_t XD;
+    int *qdims;                    // [G][2] (mym, myn) of each group's partial quadrature matrix
+    double *qwork;                 // [(G+1)*RM*RM] scratch of the quadrature tree
     GroupState *gs;            // [G]
 };

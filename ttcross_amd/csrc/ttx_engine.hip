@@ -50,6 +50,7 @@ struct ttx_engine {
     std::vector<ttx_sweep_rec> recs;
     std::vector<int32_t> tapes;         // [nsweeps-1][d+1][4]
     std::vector<int32_t> rfinal;
+    std::vector<std::vector<uint8_t>> updhist;
     int64_t neval = 0;
     double seconds = 0.0;
     bool ran = false;
@@ -61,6 +62,7 @@ struct ttx_engine {
     int64_t k_launches[TTX_K_NKINDS] = {0};
     double k_ms[TTX_K_NKINDS] = {0}, k_bytes[TTX_K_NKINDS] = {0};
     size_t lds_half = 0, lds_lot = 0, lds_par = 0;
+    int lot_batch = 1;
 };
 
 template <class T>
@@ -167,13 +169,35 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     A_(dev_alloc(h, &P.Tq, G * NC * RM * RM)); A_(dev_alloc(h, &P.qpart, G * RM * RM));
     A_(dev_alloc(h, &P.ind0, d + 2)); A_(dev_alloc(h, &P.gs, G));
     A_(dev_alloc(h, &h->d_out, G));
+    P.XD = RM * NM + RM * RM;
+    A_(dev_alloc(h, &P.sendR_h, G * XH)); A_(dev_alloc(h, &P.sendL_h, G * XH));
+    A_(dev_alloc(h, &P.sendR_i, G * (d + 2))); A_(dev_alloc(h, &P.sendL_i, G * (d + 2)));
+    A_(dev_alloc(h, &P.sendR_d, G * P.XD)); A_(dev_alloc(h, &P.sendL_d, G * P.XD));
+    A_(dev_alloc(h, &P.inL_h, G)); A_(dev_alloc(h, &P.inR_h, G)); A_(dev_alloc(h, &P.inL_i, G)); A_(dev_alloc(h, &P.inR_i, G));
+    A_(dev_alloc(h, &P.inL_d, G)); A_(dev_alloc(h, &P.inR_d, G));
+    A_(dev_alloc(h, &P.red, G * 4)); A_(dev_alloc(h, &P.qdims, G * 2)); A_(dev_alloc(h, &P.qwork, (G + 2) * RM * RM));
+    {   // neighbour message routing between groups of this GPU
+        std::vector<int *> lh(G, nullptr), rh(G, nullptr), li(G, nullptr), ri(G, nullptr);
+        std::vector<double *> ld(G, nullptr), rd(G, nullptr);
+        for (size_t g = 0; g < G; g++) {
+            if (g > 0) { lh[g] = P.sendR_h + (g - 1) * XH; li[g] = P.sendR_i + (g - 1) * (d + 2); ld[g] = P.sendR_d + (g - 1) * P.XD; }
+            if (g + 1 < G) { rh[g] = P.sendL_h + (g + 1) * XH; ri[g] = P.sendL_i + (g + 1) * (d + 2); rd[g] = P.sendL_d + (g + 1) * P.XD; }
+        }
+        HIPCHECK(hipMemcpy(P.inL_h, lh.data(), sizeof(int *) * G, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(P.inR_h, rh.data(), sizeof(int *) * G, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(P.inL_i, li.data(), sizeof(int *) * G, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(P.inR_i, ri.data(), sizeof(int *) * G, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(P.inL_d, ld.data(), sizeof(double *) * G, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(P.inR_d, rd.data(), sizeof(double *) * G, hipMemcpyHostToDevice));
+    }
 #undef A_
     HIPCHECK(hipHostMalloc((void **)&h->h_out, sizeof(HostOut) * G));
     HIPCHECK(hipHostMalloc((void **)&h->h_r, sizeof(int32_t) * G * (d + 2)));
     HIPCHECK(hipHostMalloc((void **)&h->h_tape, sizeof(int32_t) * G * (d + 2) * 4));
     h->lds_par = sizeof(double) * (cfg->npar + 2);
     h->lds_half = sizeof(double) * (cfg->npar + RM + 2) + sizeof(int) * (d + 4) + sizeof(short) * ((size_t)d * RM + 8);
-    h->lds_lot = sizeof(double) * (cfg->npar + 2 * RM + 2 * NM + 2) + sizeof(int) * 4 * (2 * RM + 2 * NM + 2);
+    {
+        const int nlotmax = 2 * h->RM + 2 * NM;
+        h->lot_batch = std::max(1, std::min(std::min(nlotmax, 512), (int)(40960 / (2 * (size_t)d))));
+        h->lds_lot = sizeof(double) * (cfg->npar + 2) + sizeof(int) * 4 * (nlotmax + 2) + sizeof(short) * ((size_t)h->lot_batch * d + 8);
+    }
     if (h->lds_half > 160 * 1024 || h->lds_lot > 64 * 1024) { ttx_destroy(h); return fail(TTX_EINVAL, "problem too large for LDS staging (d*maxrank)"); }
     *out = h;
     return TTX_OK;
@@ -223,7 +247,7 @@ __global__ void k_collect(DevProb P, HostOut *out)
     const GroupState &gs = P.gs[g];
     HostOut o;
     o.amax = gs.amax; o.pivotmax = gs.pivotmax; o.pivotmin = gs.pivotmin; o.val = gs.val; o.initval = gs.initval;
-    o.neval = gs.neval; o.bytes_half = 0.0; o.n_resid = 0;
+    o.neval = gs.neval; o.bytes_half = gs.bytes_half; o.n_resid = gs.n_resid;
     out[g] = o;
 }
 
@@ -290,6 +314,34 @@ static int readback(ttx_engine *h)
     return TTX_OK;
 }
 
+// bond ranks as the owning groups hold them (valid after readback)
+static std::vector<int32_t> global_ranks(const ttx_engine *h)
+{
+    std::vector<int32_t> r(h->d + 1, 1);
+    for (int g = 0; g < h->G; g++)
+        for (int p = h->own[h->g0 + g]; p < h->own[h->g0 + g + 1]; p++) r[p] = h->h_r[(size_t)g * (h->d + 2) + p];
+    return r;
+}
+// The reference prints erank(arg) of rank 0, whose knowledge of a bond owned by rank g lags g-1 sweeps behind
+// (the pivot tape hops one rank per sweep, lib/dmrgg.f90:768-850).  The engine ships pivots only to direct
+// neighbours, so the lag is reproduced here from the per-sweep history of accepted pivots.
+static std::vector<int32_t> rank0_view(ttx_engine *h, int it)
+{
+    const int d = h->d;
+    if (it == 0) { h->updhist.clear(); return std::vector<int32_t>(d + 1, 1); }
+    std::vector<uint8_t> u(d + 1, 0);
+    for (int g = 0; g < h->G; g++)
+        for (int p = h->own[h->g0 + g]; p < h->own[h->g0 + g + 1]; p++) u[p] = h->h_tape[((size_t)g * (d + 2) + p) * 4] > 0;
+    h->updhist.push_back(u);
+    std::vector<int32_t> r(d + 1, 1);
+    for (int g = 0; g < h->cfg.nproc; g++) {
+        int lag = std::max(0, g - 1), upto = it - lag;       // sweeps 1..upto of group g's bonds are known to rank 0
+        for (int p = h->own[g]; p < h->own[g + 1]; p++)
+            for (int t = 1; t <= upto; t++) r[p] += h->updhist[t - 1][p];
+    }
+    return r;
+}
+
 template <int FUN>
 static int run_impl(ttx_engine *h)
 {
@@ -335,7 +387,7 @@ static int run_impl(ttx_engine *h)
     auto total_neval = [&]() { long long s = 0; for (int g = 0; g < G; g++) s += h->h_out[g].neval; return s; };
     {
         ttx_sweep_rec r{};
-        r.it = 0; r.dir = 0; r.erank = erank_host(h, h->h_r); r.neval = total_neval(); r.val = val;
+        r.it = 0; r.dir = 0; r.erank = erank_host(h, rank0_view(h, 0).data()); r.neval = total_neval(); r.val = val;
         r.amax = h->h_out[0].amax; r.pivotmax = -1; r.pivotmin = -1; r.seconds = since();
         h->recs.push_back(r);
         if (h->cfg.verbose) print_line(h, r, val_prev);
@@ -351,25 +403,34 @@ static int run_impl(ttx_engine *h)
         it++;
         const int dir = 2 - it % 2;
         for (int pp = 1; pp <= h->nbmax; pp++) {
-            { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp); }
+            { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_batch); }
             for (int hh = 0; hh < h->H; hh++) {
                 KScope ks(h, TTX_K_HALFSTEP);
                 hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode);
             }
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }
-        { KScope ks(h, TTX_K_EXCHANGE); hipLaunchKernelGGL(k_sweep_end, dim3(G), dim3(64), 0, st, P); }
+        {   // per-sweep exchange between bond groups (:763-961)
+            KScope ks(h, TTX_K_EXCHANGE);
+            hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
+            hipLaunchKernelGGL(k_exch_max, dim3(1), dim3(64), 0, st, P, G);
+            if (G > 1) {
+                hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
+                hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8), st, P);
+            }
+        }
         if (P.has_quad) {
             KScope ks(h, TTX_K_QUAD);
             hipLaunchKernelGGL(k_quad_build, dim3(h->NC, G), dim3(256), lds_q, st, P, 0, P.quadw);
             hipLaunchKernelGGL(k_quad_chain, dim3(G), dim3(256), 2 * lds_q, st, P);
+            if (G > 1) hipLaunchKernelGGL(k_quad_tree, dim3(1), dim3(256), 0, st, P, (const double *)P.qpart, (const int *)P.qdims, G, P.qwork);
         }
         rc = readback(h);
         if (rc) return rc;
         HIPCHECK(hipGetLastError());
         if (P.has_quad) val = h->h_out[0].val;
         ttx_sweep_rec r{};
-        r.it = it; r.dir = dir; r.erank = erank_host(h, h->h_r); r.neval = total_neval(); r.val = val;
+        r.it = it; r.dir = dir; r.erank = erank_host(h, rank0_view(h, it).data()); r.neval = total_neval(); r.val = val;
         r.amax = h->h_out[0].amax; r.pivotmax = h->h_out[0].pivotmax; r.pivotmin = h->h_out[0].pivotmin; r.seconds = since();
         h->recs.push_back(r);
         {
@@ -387,14 +448,20 @@ static int run_impl(ttx_engine *h)
             ready = ready || (strike >= 3);
         }
     }
-    // ---- finalise (:1029) ----
+    // ---- finalise (:1029): dtt_lua shifts the rightmost inv of every group to its neighbour first ----
+    if (G > 1) {
+        KScope ks(h, TTX_K_EXCHANGE);
+        hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
+    }
     { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), 0, st, P); }
     { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), 0, st, P); }
     rc = readback(h);
     if (rc) return rc;
     HIPCHECK(hipGetLastError());
     h->neval = total_neval();
-    h->rfinal.assign(h->h_r, h->h_r + d + 1);
+    for (int g = 0; g < G; g++) h->k_bytes[TTX_K_HALFSTEP] += h->h_out[g].bytes_half;
+    h->rfinal = global_ranks(h);
     h->seconds = since();
     h->ran = true;
     return TTX_OK;
@@ -479,6 +546,7 @@ extern "C" int ttx_quad(ttx_engine *h, const double *w, double *val)
     const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
     hipLaunchKernelGGL(k_quad_build, dim3(h->NC, h->G), dim3(256), lds_q, h->stream, h->P, 1, (const double *)dw);
     hipLaunchKernelGGL(k_quad_chain, dim3(h->G), dim3(256), 2 * lds_q, h->stream, h->P);
+    if (h->G > 1) hipLaunchKernelGGL(k_quad_tree, dim3(1), dim3(256), 0, h->stream, h->P, (const double *)h->P.qpart, (const int *)h->P.qdims, h->G, h->P.qwork);
     int rc = readback(h);
     if (dw) (void)hipFree(dw);
     if (rc) return rc;

@@ -93,19 +93,49 @@ __device__ __forceinline__ double eval_fun(const DevProb &P, const double *par, 
     return f_mvn(P.d, par, P.aux, P.mvn_norm, idx);
 }
 
-// accessor over flattened tables: dims [vfrom, vto] from table vt (entry (s-vfrom)*vstride + vcol), dim
-// `self` = selfval, every other dim from fx[s]
-struct FiberIdx {
-    const short *vt; int vstride, vcol, vfrom, vto, self, selfval; const int *fx;
+// Index source of one superblock entry, split into three branch-free ranges of the flattened tables staged
+// in LDS: dims 1..A from pa (stride sa), dim A+1 = self, dims A+2..m from pb (stride sb).  This replaces the
+// reference's nested vip walk (dmrgg_fun, lib/dmrgg.f90:1062-1075): every load below is independent of the
+// arithmetic chains, so the compiler can keep them in flight ahead of the dependent fp64 products.
+struct Src3 {
+    const short *pa; int sa, A, self; const short *pb; int sb;
     __device__ __forceinline__ int operator()(int s) const
-    { return (s == self) ? selfval : (s >= vfrom && s <= vto) ? (int)vt[(s - vfrom) * vstride + vcol] : fx[s]; }
+    { return (s <= A) ? (int)pa[(s - 1) * sa] : (s == A + 1) ? self : (int)pb[(s - A - 2) * sb]; }
 };
-// accessor for one superblock entry (i,j,k,q) at bond p straight from the global tables (dmrgg_fun)
-struct EntryIdx {
-    const short *Lt, *Rt; int RM, p, i, j, k, q;   // i,q 0-based pivot ids; j,k 1-based mode indices
-    __device__ __forceinline__ int operator()(int s) const
-    { return s < p ? (int)Lt[(s - 1) * RM + i] : (s == p) ? j : (s == p + 1) ? k : (int)Rt[(s - p - 2) * RM + q]; }
-};
+
+// Ising C (id 1) over a Src3: identical arithmetic to f_ising (the v- and w-recurrences of
+// test_crs_ising.f90:199-204 are independent, so running them as separate loops changes nothing)
+__device__ __forceinline__ double f_ising_c3(int m, int n1, const double *par, const Src3 &S)
+{
+    const double *nodes = par - 1, *weights = par + n1 - 1;
+    const int A = S.A, nb = m - A - 1;
+    double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
+#pragma unroll 4
+    for (int x = nb - 1; x >= 0; x--) { vk = vk * nodes[S.pb[x * S.sb]]; v = v + vk; }
+    vk = vk * nodes[S.self]; v = v + vk;
+#pragma unroll 4
+    for (int x = A - 1; x >= 0; x--) { vk = vk * nodes[S.pa[x * S.sa]]; v = v + vk; }
+#pragma unroll 4
+    for (int x = 0; x < A; x++) { wk = wk * nodes[S.pa[x * S.sa]]; w = w + wk; }
+    wk = wk * nodes[S.self]; w = w + wk;
+#pragma unroll 4
+    for (int x = 0; x < nb; x++) { wk = wk * nodes[S.pb[x * S.sb]]; w = w + wk; }
+    double b = 1.0 / (v * w);
+    double f = 2 * b;
+#pragma unroll 4
+    for (int x = 0; x < A; x++) f = f * weights[S.pa[x * S.sa]];
+    f = f * weights[S.self];
+#pragma unroll 4
+    for (int x = 0; x < nb; x++) f = f * weights[S.pb[x * S.sb]];
+    return f;
+}
+
+template <int FUN>
+__device__ __forceinline__ double eval_src3(const DevProb &P, const double *par, const Src3 &S)
+{
+    if (FUN == FUN_ISING && P.ising_id == 1) return f_ising_c3(P.d, P.n[1], par, S);
+    return eval_fun<FUN>(P, par, S);
+}
 
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
@@ -312,7 +342,7 @@ __global__ void k_init_final(DevProb P)
 // one block per group
 // ------------------------------------------------------------------------------------------------
 template <int FUN>
-__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
+__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int LB)
 {
     extern __shared__ double dyn[];
     __shared__ StepState st;
@@ -342,8 +372,10 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
     if (!st.active) { if (tid == 0) gs.S[0] = st; return; }
     const int p = st.p, r0 = st.r0, r1 = st.r1, r2 = st.r2, n1 = st.n1, n2 = st.n2, first = gs.first;
     const int nlot = r0 + n1 + n2 + r2;
-    double *par = dyn, *bval = dyn + P.npar;
-    int *lot = (int *)(bval + nlot);
+    // LDS: par | lot[4*nlot] (int) | rows[LB*m] (short)
+    double *par = dyn;
+    int *lot = (int *)(dyn + P.npar);
+    short *rows = (short *)(lot + 4 * nlot);
     for (int x = tid; x < P.npar; x += blockDim.x) par[x] = P.par[x];
     // zero-weight positions (existing pivots), :432-439
     const int *vp = vip_ptr(P, g, p, first);
@@ -375,28 +407,45 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
     if (tid == 0) nsc = ttx_cdf_build(Kc, segc);
     if (tid == 64) nsr = ttx_cdf_build(Kr, segr);
     __syncthreads();
+    // rnd.f90:120-124: d(nlot,2) column-major from the (never seeded) run-time generator; :447-452 decode
+    for (int il = tid; il < nlot; il += blockDim.x) {
+        double d1 = ttx_flang_draw(gs.rngpos + il), d2 = ttx_flang_draw(gs.rngpos + nlot + il);
+        int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);
+        int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
+        lot[4 * il] = (x - 1) % r0 + 1; lot[4 * il + 1] = (x - 1) / r0 + 1;
+        lot[4 * il + 2] = (y - 1) % n2 + 1; lot[4 * il + 3] = (y - 1) / n2 + 1;
+    }
+    __syncthreads();
     const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
     const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
     double ma = 0.0;
     double ba = -1.0, bv = 0.0; int bi = INT_MAX;
-    for (int il = tid; il < nlot; il += blockDim.x) {
-        // rnd.f90:120-124: d(nlot,2) column-major from the (never seeded) run-time generator
-        double d1 = ttx_flang_draw(gs.rngpos + il), d2 = ttx_flang_draw(gs.rngpos + nlot + il);
-        int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);
-        int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
-        int j = (x - 1) / r0 + 1, i = (x - 1) % r0 + 1;          // :447-452
-        int q = (y - 1) / n2 + 1, k = (y - 1) % n2 + 1;
-        lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
-        EntryIdx ix{Lt, Rt, P.RM, p, i - 1, j, k, q - 1};
-        double f = eval_fun<FUN>(P, par, ix);                    // :455-463
-        ma = fmax(ma, fabs(f));
-        const double *c = Cp + (i - 1) + (size_t)P.RM * (j - 1), *w = Wq + (k - 1) + (size_t)P.NM * (q - 1);
-        double t = 0.0;                                          // ddot, :474
-        for (int s = 0; s < r1; s++) t = t + c[P.SS * s] * w[P.SW * s];
-        double b = f - t;
-        bval[il] = b;
-        double a = fabs(b);
-        if (a > ba || (a == ba && il < bi)) { ba = a; bv = b; bi = il; }
+    for (int b0 = 0; b0 < nlot; b0 += LB) {
+        const int nbat = min(LB, nlot - b0);
+        // stage the full multi-index of every candidate of the batch: independent, pipelined loads
+        for (int x = tid; x < nbat * m; x += blockDim.x) {
+            int il = b0 + x / m, s = x % m + 1;
+            int i = lot[4 * il] - 1, q = lot[4 * il + 3] - 1;
+            rows[x] = (s < p) ? Lt[(size_t)(s - 1) * P.RM + i] : (s == p) ? (short)lot[4 * il + 1]
+                    : (s == p + 1) ? (short)lot[4 * il + 2] : Rt[(size_t)(s - p - 2) * P.RM + q];
+        }
+        __syncthreads();
+        if (tid < nbat) {
+            const int il = b0 + tid;
+            const short *row = rows + (size_t)tid * m;
+            Src3 sx{row, 1, p - 1, (int)row[p - 1], row + p, 1};
+            double f = eval_src3<FUN>(P, par, sx);                   // :455-463
+            ma = fmax(ma, fabs(f));
+            int i = lot[4 * il], j = lot[4 * il + 1], k = lot[4 * il + 2], q = lot[4 * il + 3];
+            const double *c = Cp + (i - 1) + (size_t)P.RM * (j - 1), *w = Wq + (k - 1) + (size_t)P.NM * (q - 1);
+            double t = 0.0;                                          // ddot, :474
+#pragma unroll 8
+            for (int s = 0; s < r1; s++) t = t + c[P.SS * s] * w[P.SW * s];
+            double b = f - t;
+            double a = fabs(b);
+            if (a > ba || (a == ba && il < bi)) { ba = a; bv = b; bi = il; }
+        }
+        __syncthreads();
     }
     ma = block_max(ma, sha);
     block_argmax(ba, bv, bi, sha, shv, shi);
@@ -432,23 +481,23 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
     const int nf = iscol ? r0 * n1 : n2 * r2;
     if (blockIdx.x * TTX_BLK >= nf) return;
-    // LDS: par | xs[RM] | fx[d+2] (int) | vt[d*RM] (short)
+    // LDS: par | xs[RM] | fxs[d+2] (short) | vt[d*RM] (short)
     double *par = dyn, *xs = dyn + P.npar;
-    int *fx = (int *)(xs + P.RM);
-    short *vt = (short *)(fx + m + 2);
+    short *fxs = (short *)(xs + P.RM);
+    short *vt = fxs + ((m + 2 + 3) & ~3);
     const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
     const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
     for (int x = tid; x < P.npar; x += TTX_BLK) par[x] = P.par[x];
     int vrows, vcols;
-    if (iscol) {   // varying: left pivot i (dims 1..p-1) and j; fixed: kk and the right multi-index of qq
+    if (iscol) {   // varying: left pivot i (dims 1..p-1) and j; fixed: kk and the right multi-index of qq (dims p+1..m)
         vrows = p - 1; vcols = r0;
         for (int x = tid; x < vrows * vcols; x += TTX_BLK) vt[x] = Lt[(size_t)(x / vcols) * P.RM + (x % vcols)];
-        for (int s = p + 1 + tid; s <= m; s += TTX_BLK) fx[s] = (s == p + 1) ? cur.kk : (int)Rt[(size_t)(s - p - 2) * P.RM + (cur.qq - 1)];
+        for (int x = tid; x < m - p; x += TTX_BLK) fxs[x] = (x == 0) ? (short)cur.kk : Rt[(size_t)(x - 1) * P.RM + (cur.qq - 1)];
         for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Wq[(cur.kk - 1) + (size_t)P.NM * (cur.qq - 1) + P.SW * s];
-    } else {       // varying: k and right pivot q (dims p+2..m); fixed: left multi-index of ii and jj
+    } else {       // varying: k and right pivot q (dims p+2..m); fixed: left multi-index of ii and jj (dims 1..p)
         vrows = m - p - 1; vcols = r2;
         for (int x = tid; x < vrows * vcols; x += TTX_BLK) vt[x] = Rt[(size_t)(x / vcols) * P.RM + (x % vcols)];
-        for (int s = 1 + tid; s <= p; s += TTX_BLK) fx[s] = (s == p) ? cur.jj : (int)Lt[(size_t)(s - 1) * P.RM + (cur.ii - 1)];
+        for (int x = tid; x < p; x += TTX_BLK) fxs[x] = (x == p - 1) ? (short)cur.jj : Lt[(size_t)x * P.RM + (cur.ii - 1)];
         for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Cp[(cur.ii - 1) + (size_t)P.RM * (cur.jj - 1) + P.SS * s];
     }
     __syncthreads();
@@ -457,12 +506,10 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     double a = 0.0;
     int u = 0, v = 0;                         // col: (i,j) 0-based ; row: (k,q) 0-based
     if (live) {
-        if (iscol) { u = t % r0; v = t / r0; } else { u = t % n2; v = t / n2; }
-        FiberIdx ix;
-        ix.vt = vt; ix.vstride = vcols; ix.fx = fx;
-        if (iscol) { ix.vcol = u; ix.vfrom = 1; ix.vto = p - 1; ix.self = p; ix.selfval = v + 1; }
-        else       { ix.vcol = v; ix.vfrom = p + 2; ix.vto = m; ix.self = p + 1; ix.selfval = u + 1; }
-        a = eval_fun<FUN>(P, par, ix);                                        // :520-526 / :553-559
+        Src3 sx;
+        if (iscol) { u = t % r0; v = t / r0; sx.pa = vt + u; sx.sa = vcols; sx.A = p - 1; sx.self = v + 1; sx.pb = fxs; sx.sb = 1; }
+        else       { u = t % n2; v = t / n2; sx.pa = fxs; sx.sa = 1; sx.A = p; sx.self = u + 1; sx.pb = vt + v; sx.sb = vcols; }
+        a = eval_src3<FUN>(P, par, sx);                                       // :520-526 / :553-559
         (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
     }
     double mx = block_max(live ? fabs(a) : 0.0, sha);
@@ -496,6 +543,9 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
         nx.pending = resid ? (iscol ? 1 : 2) : 0;
         gs.S[h + 1] = nx;
         gs.neval += nf;                                                       // :527 / :560 / :509
+        // algorithmic traffic: factor slabs + vector + fiber in/out when a residual is taken, else the fiber
+        gs.bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
+        gs.n_resid += resid ? 1 : 0;
     }
 }
 
@@ -613,13 +663,6 @@ __global__ __launch_bounds__(TTX_BLK) void k_accept(DevProb P, int H, int nA)
     }
 }
 
-// per-sweep bookkeeping for a single group (:961); the multi-group exchange kernels set it themselves
-__global__ void k_sweep_end(DevProb P)
-{
-    GroupState &gs = P.gs[blockIdx.x];
-    if (threadIdx.x == 0) gs.pivotmax_prev = gs.pivotmax;
-}
-
 // ------------------------------------------------------------------------------------------------
 // quadrature (lib/dmrgg.f90:975-993 per sweep, :1261-1415 dtt_quad) and finalisation dtt_lua (:1169-1258)
 // ------------------------------------------------------------------------------------------------
@@ -701,7 +744,7 @@ __global__ __launch_bounds__(256) void k_quad_chain(DevProb P)
     const int myn = r[lastc];
     double *out = P.qpart + (size_t)g * RM * RM;
     for (int x = tid; x < mym * myn; x += blockDim.x) out[(x % mym) + RM * (x / mym)] = prev[(x % mym) + RM * (x / mym)];
-    if (P.nprocs == 1 && tid == 0) gs.val = prev[0];
+    if (tid == 0) { P.qdims[2 * g] = mym; P.qdims[2 * g + 1] = myn; if (P.nprocs == 1) gs.val = prev[0]; }
 }
 
 // dtt_lua on the raw fibers: luar pass then lual pass (two launches: the second needs the whole core)
@@ -793,4 +836,207 @@ __global__ void k_lottery_only(int npnt, int m, int n, int nz, const int *zcol, 
         points[il] = ttx_lottery_index(segc, nsc, m - nz, m, zcol, nz, d1);
         points[npnt + il] = ttx_lottery_index(segr, nsr, n - nz, n, zrow, nz, d2);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-sweep neighbour exchange between bond groups (lib/dmrgg.f90:763-958; the right-going block lost in
+// the fp64 source is restated from lib/dmrggmp.f90:572-629).  Instead of propagating the 4-int pivot tape
+// through every rank (which makes far bonds lag by one sweep per hop), the owner ships the FLATTENED
+// multi-index of its new boundary pivot to its direct neighbour -- the only rank that ever evaluates with it.
+// ------------------------------------------------------------------------------------------------
+#define XH 8
+// one block per group: pack both outgoing messages and the group's entry of the MAX all-reduce
+__global__ __launch_bounds__(256) void k_exch_pack(DevProb P)
+{
+    const int g = blockIdx.x, tid = threadIdx.x, m = P.d;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first, last = gs.last;
+    const int *r = P.r + (size_t)g * (m + 2), *rr = P.rr + (size_t)g * (m + 2), *upd = P.upd + (size_t)g * (m + 2);
+    if (tid == 0) {
+        double *red = P.red + (size_t)g * 4;
+        red[0] = gs.amax; red[1] = gs.pivotmax; red[2] = (gs.pivotmin > 0.0) ? -gs.pivotmin : -999e9;   // :853-859
+    }
+    {   // to the right neighbour: own last bond q = last, boundary core q+1
+        const int q = last, u = upd[q];
+        int *hh = P.sendR_h + (size_t)g * XH; int *ix = P.sendR_i + (size_t)g * (m + 2); double *dd = P.sendR_d + (size_t)g * P.XD;
+        if (tid == 0) { hh[0] = u; hh[1] = r[q]; }
+        const int rq = r[q];
+        const double *gI = inv_ptr(P, g, q, first);
+        for (int x = tid; x < rq * rq; x += blockDim.x) dd[(size_t)P.RM * P.NM + x] = gI[x];           // inv(q) for dtt_lua, :1225
+        if (u) {
+            const short *Lt = L_ptr(P, g, q, first);
+            for (int x = tid; x < q; x += blockDim.x) ix[x] = Lt[(size_t)x * P.RM + (rq - 1)];
+            // newest row of core q+1: arg(q+1)(r(q), :, 1:rr(q+1))  (dmrggmp.f90:580)
+            const double *A = core_ptr(P, P.arg, g, q + 1, first);
+            const int n2 = P.n[q + 1], rrq1 = rr[q + 1];
+            for (int x = tid; x < n2 * rrq1; x += blockDim.x) dd[x] = A[(rq - 1) + (size_t)P.RM * (x % n2) + P.SS * (x / n2)];
+        }
+    }
+    {   // to the left neighbour: own first bond q = first, boundary core q
+        const int q = first, u = upd[q];
+        int *hh = P.sendL_h + (size_t)g * XH; int *ix = P.sendL_i + (size_t)g * (m + 2); double *dd = P.sendL_d + (size_t)g * P.XD;
+        if (tid == 0) { hh[0] = u; hh[1] = r[q]; }
+        if (u) {
+            const int rq = r[q];
+            const short *Rt = R_ptr(P, g, q, first);
+            for (int x = tid; x < m - q; x += blockDim.x) ix[x] = Rt[(size_t)x * P.RM + (rq - 1)];
+            // newest column of core q: arg(q)(1:rr(q-1), :, r(q))  (dmrgg.f90:889)
+            const double *A = core_ptr(P, P.arg, g, q, first);
+            const int n1 = P.n[q], rr0 = rr[q - 1];
+            for (int x = tid; x < rr0 * n1; x += blockDim.x) dd[x] = A[(x % rr0) + (size_t)P.RM * (x / rr0) + P.SS * (rq - 1)];
+        }
+    }
+}
+
+// MAX all-reduce over the groups of this GPU (:861); nred = number of entries in P.red (local groups, or
+// 1 after an RCCL all-reduce has already combined all GPUs into entry 0)
+__global__ void k_exch_max(DevProb P, int nred)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double a = -1e300, b = -1e300, c = -1e300;
+    for (int g = 0; g < nred; g++) { a = fmax(a, P.red[4 * g]); b = fmax(b, P.red[4 * g + 1]); c = fmax(c, P.red[4 * g + 2]); }
+    for (int g = 0; g < P.G; g++) {
+        GroupState &gs = P.gs[g];
+        gs.amax = a; gs.pivotmax = b; gs.pivotmin = (-c == 999e9) ? -1.0 : -c;     // :867-870
+        gs.pivotmax_prev = b;                                                      // :961
+    }
+}
+
+// apply the neighbours' pivots: ranks, index tables, inv of the left boundary bond (:822-850, :1209-1246)
+__global__ __launch_bounds__(256) void k_exch_apply(DevProb P)
+{
+    const int g = blockIdx.x, tid = threadIdx.x, m = P.d;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first, last = gs.last;
+    int *r = P.r + (size_t)g * (m + 2), *upd = P.upd + (size_t)g * (m + 2);
+    if (P.inL_h[g]) {
+        const int bl = first - 1;
+        const int *hh = P.inL_h[g], *ix = P.inL_i[g]; const double *dd = P.inL_d[g];
+        const int u = hh[0], rnew = hh[1];
+        if (u) { short *Lt = L_ptr(P, g, bl, first); for (int x = tid; x < bl; x += blockDim.x) Lt[(size_t)x * P.RM + (rnew - 1)] = (short)ix[x]; }
+        double *gI = inv_ptr(P, g, bl, first);
+        for (int x = tid; x < rnew * rnew; x += blockDim.x) gI[x] = dd[(size_t)P.RM * P.NM + x];
+        if (tid == 0) { upd[bl] = u; r[bl] = rnew; }
+    }
+    if (P.inR_h[g]) {
+        const int br = last + 1;
+        const int *hh = P.inR_h[g], *ix = P.inR_i[g];
+        const int u = hh[0], rnew = hh[1];
+        if (u) { short *Rt = R_ptr(P, g, br, first); for (int x = tid; x < m - br; x += blockDim.x) Rt[(size_t)x * P.RM + (rnew - 1)] = (short)ix[x]; }
+        if (tid == 0) { upd[br] = u; r[br] = rnew; }
+    }
+}
+
+// grow the boundary cores with the neighbours' fibers, evaluate the corner entries, LU-apply
+// blocks [0,NM): "share blocks to the LEFT" receive side (:912-952), one mode index k each;
+// blocks [NM,2NM): "share blocks to the RIGHT" receive side (dmrggmp.f90:598-627), one mode index j each
+template <int FUN>
+__global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
+{
+    extern __shared__ double dyn[];
+    __shared__ double s_bc;
+    const int g = blockIdx.y, tid = threadIdx.x, m = P.d;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first, last = gs.last;
+    const int *r = P.r + (size_t)g * (m + 2), *rr = P.rr + (size_t)g * (m + 2), *upd = P.upd + (size_t)g * (m + 2);
+    double *par = dyn;
+    short *row = (short *)(dyn + P.npar);      // one full multi-index (m shorts) for the corner evaluation
+    if ((int)blockIdx.x < P.NM) {
+        const int k = blockIdx.x, p = last, br = last + 1;
+        if (!P.inR_h[g] || !upd[br] || k >= P.n[br]) return;
+        const int rp = r[p], rrp = rr[p], snew = r[br] - 1, n2 = P.n[br];
+        const double *msg = P.inR_d[g];                              // (rr(p), n(p+1))
+        double *A = core_ptr(P, P.arg, g, br, first), *W = core_ptr(P, P.row, g, br, first);
+        double a = 0.0;
+        if (tid < rrp) a = msg[tid + (size_t)rrp * k];
+        if (upd[p]) {                                                // corner arg(p+1)(r(p), k, r(p+1)), :925-937
+            for (int x = tid; x < P.npar; x += TTX_BLK) par[x] = P.par[x];
+            const int *vp = vip_ptr(P, g, p, first) + 4 * (rp - 1);
+            const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, br, first);
+            for (int s = 1 + tid; s <= m; s += TTX_BLK)
+                row[s - 1] = (s < p) ? Lt[(size_t)(s - 1) * P.RM + (vp[0] - 1)] : (s == p) ? (short)vp[1] : (s == p + 1) ? (short)(k + 1) : Rt[(size_t)(s - p - 2) * P.RM + snew];
+            __syncthreads();
+            if (tid == rrp) {
+                Src3 sx{row, 1, p - 1, (int)row[p - 1], row + p, 1};
+                a = eval_src3<FUN>(P, par, sx);
+                atomic_max_pos(&gs.amax, fabs(a));
+                if (k == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n2);   // :936
+            }
+        }
+        if (tid < rp) A[tid + (size_t)P.RM * k + P.SS * snew] = a;
+        // row(p+1)(:, k, new) = L(p)^-1 * column : d2_luar(n(p+1), r(p), inv(p), .) :940-951
+        const double *gI = inv_ptr(P, g, p, first);
+        double tmp = 0.0, xf = 0.0;
+        for (int s = 0; s < rp; s++) {
+            if (tid == s) { xf = (s == 0) ? a : a + (-1.0) * tmp; s_bc = xf; }
+            __syncthreads();
+            if (tid > s && tid < rp) tmp = tmp + s_bc * gI[tid * tid + s];
+            __syncthreads();
+        }
+        if (tid < rp) W[k + (size_t)P.NM * snew + P.SW * tid] = xf;
+    } else {
+        const int j = blockIdx.x - P.NM, p = first, bl = first - 1;
+        if (!P.inL_h[g] || !upd[bl] || j >= P.n[p]) return;
+        const int rp = r[p], rrp = rr[p], inew = r[bl] - 1, n1 = P.n[p];
+        const double *msg = P.inL_d[g];                              // (n(p), rr(p))
+        double *A = core_ptr(P, P.arg, g, p, first), *C = core_ptr(P, P.col, g, p, first);
+        double y = 0.0;
+        if (tid < rrp) y = msg[j + (size_t)n1 * tid];
+        if (upd[p]) {                                                // corner arg(p)(r(p-1), j, r(p)), dmrggmp.f90:608-616
+            for (int x = tid; x < P.npar; x += TTX_BLK) par[x] = P.par[x];
+            const int *vp = vip_ptr(P, g, p, first) + 4 * (rp - 1);
+            const short *Lt = L_ptr(P, g, bl, first), *Rt = R_ptr(P, g, p + 1, first);
+            for (int s = 1 + tid; s <= m; s += TTX_BLK)
+                row[s - 1] = (s < p) ? Lt[(size_t)(s - 1) * P.RM + inew] : (s == p) ? (short)(j + 1) : (s == p + 1) ? (short)vp[2] : Rt[(size_t)(s - p - 2) * P.RM + (vp[3] - 1)];
+            __syncthreads();
+            if (tid == rrp) {
+                Src3 sx{row, 1, p - 1, (int)row[p - 1], row + p, 1};
+                y = eval_src3<FUN>(P, par, sx);
+                atomic_max_pos(&gs.amax, fabs(y));
+                if (j == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n1);
+            }
+        }
+        if (tid < rp) A[inew + (size_t)P.RM * j + P.SS * tid] = y;
+        // col(p)(new, j, :) = row * U(p)^-1 : d2_lual(n(p), r(p), inv(p), .) dmrggmp.f90:622
+        const double *gI = inv_ptr(P, g, p, first);
+        for (int s = 0; s < rp; s++) {
+            if (tid == s) { y = (1.0 / gI[(s + 1) * (s + 1) - 1]) * y; s_bc = y; }
+            __syncthreads();
+            if (tid > s && tid < rp) y = y + (-gI[tid * tid + tid + s]) * s_bc;
+            __syncthreads();
+        }
+        if (tid < rp) C[inew + (size_t)P.RM * j + P.SS * tid] = y;
+    }
+}
+
+// binary-tree product of the groups' partial quadrature matrices (lib/dmrgg.f90:1355-1405); single block.
+// part[g] is RM x RM padded; dims[2g], dims[2g+1] = (mym, myn) of group g; ng = number of groups
+__global__ __launch_bounds__(256) void k_quad_tree(DevProb P, const double *part, const int *dims, int ng, double *work)
+{
+    const int tid = threadIdx.x, RM = P.RM;
+    __shared__ int mym[256], myn[256];
+    for (int g = tid; g < ng; g += blockDim.x) { mym[g] = dims[2 * g]; myn[g] = dims[2 * g + 1]; }
+    for (int x = tid; x < ng * RM * RM; x += blockDim.x) work[x] = part[x];
+    __syncthreads();
+    double *tmp = work + (size_t)ng * RM * RM;
+    for (int q = 1; q < ng; q *= 2) {
+        for (int me = 0; me + q < ng; me += 2 * q) {
+            const int her = me + q;
+            const double *Aa = work + (size_t)me * RM * RM, *Bb = work + (size_t)her * RM * RM;
+            const int mm = mym[me], kk = myn[me], nn = myn[her];
+            for (int x = tid; x < mm * nn; x += blockDim.x) {
+                int i = x % mm, j = x / mm;
+                double c = 0.0;
+                for (int l = 0; l < kk; l++) c = c + Bb[l + RM * j] * Aa[i + RM * l];     // dgemm 'n','n', :1381
+                tmp[i + RM * j] = c;
+            }
+            __syncthreads();
+            double *dst = work + (size_t)me * RM * RM;
+            for (int x = tid; x < mm * nn; x += blockDim.x) dst[(x % mm) + RM * (x / mm)] = tmp[(x % mm) + RM * (x / mm)];
+            __syncthreads();
+            if (tid == 0) myn[me] = nn;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) P.gs[0].val = work[0];
 }
