@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c64", choices=sorted(WORKLOADS))
-    ap.add_argument("--groups", type=int, default=0, help="bond groups (virtual MPI ranks of the reference); default = gpus")
+    ap.add_argument("--groups", type=int, default=0, help="bond groups = MPI ranks of the reference's domain split; default 8 (config 3 of BASELINE.json) at every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -108,7 +108,7 @@ def main():
 
     argv, desc = WORKLOADS[a.workload]
     s = D.ising_setup(argv[1], argv[2], argv[3])
-    groups = a.groups or world
+    groups = a.groups or max(8, world)
     tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
                    nproc=groups, device=local, world_rank=rank, world_size=world) if world > 1 else \
         E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
