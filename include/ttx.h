@@ -81,6 +81,17 @@ void ttx_destroy(ttx_engine *h);
 int ttx_comm_unique_id(uint8_t id[128]);
 int ttx_comm_init(ttx_engine *h, const uint8_t id[128]);
 
+/* Alternative transport for world_size > 1 when RCCL cannot be used (and for multi-process tests on one GPU):
+ * the host layer supplies MPI-like primitives on HOST buffers; the engine stages messages through pinned memory.
+ * sendrecv: send ns bytes to rank `to` (skip if to < 0) and receive nr bytes from rank `from` (skip if < 0);
+ * allreduce: in place on `count` doubles, op 0 = sum, 1 = max.  Both return 0 on success. */
+typedef struct ttx_transport {
+    void *ctx;
+    int (*sendrecv)(void *ctx, int to, const void *sbuf, int64_t ns, int from, void *rbuf, int64_t nr);
+    int (*allreduce)(void *ctx, double *buf, int64_t count, int op);
+} ttx_transport;
+int ttx_set_transport(ttx_engine *h, const ttx_transport *t);
+
 /* dtt_dmrgg itself: initial cross, sweeps until maxrank / 3 strikes, finalisation dtt_lua (lib/dmrgg.f90:151-1049) */
 int ttx_run(ttx_engine *h);
 

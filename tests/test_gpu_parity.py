@@ -131,3 +131,20 @@ def test_lottery_bit_exact():
         want = O.lottery2(npnt, wc, wr, draws)
         got = E.k_lottery(npnt, m, n, zc, zr, rngpos=pos)
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,args", [(2, "c 6 33 20 2 4"), (2, "c 64 51 32 2 8"), (3, "d 8 33 10 2 3"), (4, "c 16 51 32 2 8")],
+                         ids=["w2_c6_g4", "w2_c64_g8", "w3_d8_g3", "w4_c16_g8"])
+def test_multi_process_bond_split(world, args):
+    """The N>1 path: `world` engine processes (one per GPU in production; here they share the card, <= 4 ranks)
+    split the bond groups and exchange through the transport layer; bit-identical to the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + world), os.path.join(root, "tests", "mp_worker.py")] + args.split() + ["gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count(" OK") == world

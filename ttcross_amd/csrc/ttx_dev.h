@@ -21,6 +21,16 @@
 #define TTX_MAXH 24        // half-step state slots (2*piv+2 <= TTX_MAXH)
 #define TTX_MAXPART 512    // partial arg-max records per half-step (blocks per fiber)
 #define TTX_BLK 256
+#define XH 8             // ints in a message header
+// layout of the per-sweep summary (doubles): scalars, then initval per global group, then (r, tape[4]) per bond
+#define SUM_NEVAL 0
+#define SUM_AMAX 1
+#define SUM_PMAX 2
+#define SUM_PMIN 3
+#define SUM_BYTES 4
+#define SUM_NRESID 5
+#define SUM_VAL 6
+#define SUM_HDR 8
 
 struct StepState {
     int active;            // this group has a bond at this step of the sweep
@@ -72,19 +82,21 @@ struct DevProb {
     int *r, *rr, *upd, *tape;  // [G][d+2] (tape x4)
     double *acol, *arow;       // [G][RM*NM]
     double *Tq;                // [G][NC][RM*RM]
-    double *qpart;             // [G][RM*RM]
     int *ind0;                 // [d+2] initial cross index
     // per-sweep neighbour exchange (lib/dmrgg.f90:763-958 + lib/dmrggmp.f90:572-629).  Each group packs one
-    // message for its right and one for its left neighbour; in* point at the message to consume: the
-    // neighbour's send buffer when it lives on this GPU, an RCCL receive buffer otherwise.
-    int *sendR_h, *sendL_h;        // [G][XH]      header: upd, tape(4), new rank
-    int *sendR_i, *sendL_i;        // [G][d+2]     full multi-index of the new boundary pivot
-    double *sendR_d, *sendL_d;     // [G][XD]      boundary fiber (+ inv for the right-going message)
-    int **inL_h, **inR_h, **inL_i, **inR_i;   // [G] message from the left / right neighbour (nullptr: none)
-    double **inL_d, **inR_d;
-    double *red;                   // [G][4] amax, pivotmax, -pivotmin (for the MAX all-reduce, :852-870)
-    size_t XD;
-    int *qdims;                    // [G][2] (mym, myn) of each group's partial quadrature matrix
-    double *qwork;                 // [(G+1)*RM*RM] scratch of the quadrature tree
+    // contiguous message for its right and one for its left neighbour:
+    //   [XH int header: upd, new rank][d+2 int: flattened multi-index of the new boundary pivot]
+    //   [XD double: boundary fiber (RM*NM) + packed inv (RM*RM, right-going only)]
+    // inL/inR[g] point at the message group g consumes: the neighbour's send buffer when it lives on this GPU,
+    // the RCCL receive buffer otherwise (nullptr: no neighbour).
+    char *msgR, *msgL;             // [G][MSZ]
+    char **inL, **inR;             // [G]
+    size_t MSZ, IOFF, XD;          // message bytes, byte offset of the double payload, doubles in the payload
+    double *red;                   // [G][4] amax, pivotmax, -pivotmin per group (MAX all-reduce, :852-870)
+    double *redsend, *redrecv;     // [4] this GPU's entry / the job-wide result
+    double *qsend, *qall;          // [nprocs*RM*RM + 2*nprocs] partial matrices + dims of ALL groups (SUM all-reduce)
+    double *qwork;                 // [(nprocs+2)*RM*RM] scratch of the quadrature tree
+    double *sumsend, *sumrecv;     // per-sweep job summary (SUM all-reduce): see SUM_* offsets
+    int g0;                        // global index of local group 0
     GroupState *gs;            // [G]
 };

@@ -16,6 +16,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the library is dlopen()ed by ttx_comm_init
+
 #include "../../include/ttx.h"
 #include "ttx_kernels.h"
 
@@ -32,7 +35,36 @@ static int fail(int code, const char *fmt, ...)
 extern "C" const char *ttx_last_error(void) { return g_err.c_str(); }
 extern "C" int ttx_version(void) { return 1; }
 
-struct HostOut { double amax, pivotmax, pivotmin, val, initval, bytes_half; long long neval, n_resid; };
+
+// RCCL entry points, resolved at run time (single-GPU users never load librccl)
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load()
+{
+    if (g_rccl.lib) return TTX_OK;
+    void *L = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!L) L = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!L) return fail(TTX_EHIP, "cannot load librccl.so: %s", dlerror());
+#define SYM_(f, name) *(void **)(&g_rccl.f) = dlsym(L, name); if (!g_rccl.f) return fail(TTX_EHIP, "librccl.so lacks %s", name);
+    SYM_(GetUniqueId, "ncclGetUniqueId") SYM_(CommInitRank, "ncclCommInitRank") SYM_(CommDestroy, "ncclCommDestroy")
+    SYM_(Send, "ncclSend") SYM_(Recv, "ncclRecv") SYM_(AllReduce, "ncclAllReduce") SYM_(GroupStart, "ncclGroupStart")
+    SYM_(GroupEnd, "ncclGroupEnd") SYM_(GetErrorString, "ncclGetErrorString")
+#undef SYM_
+    g_rccl.lib = L;
+    return TTX_OK;
+}
+#define NCCLCHECK(x) do { ncclResult_t e_ = (x); if (e_ != ncclSuccess) return fail(TTX_EHIP, "%s failed: %s", #x, g_rccl.GetErrorString(e_)); } while (0)
 
 struct ttx_engine {
     ttx_config cfg;
@@ -41,12 +73,19 @@ struct ttx_engine {
     std::vector<int32_t> own;           // own[0..nproc]
     int d = 0, RM = 0, NM = 0, G = 0, NC = 0, nbmax = 0, H = 0, mode = 0;
     int g0 = 0;                         // first global group held by this process
+    int W = 1, wrank = 0;               // processes (GPUs) of the job, my index
     DevProb P{};
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
-    HostOut *h_out = nullptr;           // pinned [G]
-    int32_t *h_r = nullptr, *h_tape = nullptr;   // pinned
-    HostOut *d_out = nullptr;
+    size_t SB = 0, QB = 0;              // doubles in the summary / quadrature gather buffers
+    double *h_sum = nullptr;            // pinned [SB]
+    char *h_msg = nullptr;              // pinned 4*MSZ (host-callback transport staging)
+    double *h_tmp = nullptr;            // pinned max(QB, SB)
+    char *recvL = nullptr, *recvR = nullptr;   // device receive buffers for remote neighbours
+    // transports between GPUs: RCCL (device buffers, stream-ordered) or host callbacks (staged through pinned memory)
+    ncclComm_t comm = nullptr;
+    ttx_transport cb{};
+    bool have_cb = false;
     std::vector<ttx_sweep_rec> recs;
     std::vector<int32_t> tapes;         // [nsweeps-1][d+1][4]
     std::vector<int32_t> rfinal;
@@ -56,7 +95,7 @@ struct ttx_engine {
     bool ran = false;
     // profiling
     bool profile = false;
-    struct Ev { int kind; hipEvent_t a, b; };
+    struct Ev { int kind, n; hipEvent_t a, b; };
     std::vector<Ev> evs;
     std::vector<hipEvent_t> evpool;
     int64_t k_launches[TTX_K_NKINDS] = {0};
@@ -101,9 +140,12 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     if (cfg->pivoting < 0) return fail(TTX_EINVAL, "dtt_dmrgg: pivoting %d (full superblock search) is not available in this build", cfg->pivoting);
     if (2 * cfg->pivoting + 2 > TTX_MAXH) return fail(TTX_EINVAL, "dtt_dmrgg: pivoting %d too large", cfg->pivoting);
     if (cfg->fun_id < 1 || cfg->fun_id > 3) return fail(TTX_EINVAL, "ttx_create: unknown fun_id %d", cfg->fun_id);
-    const int nproc = cfg->nproc < 1 ? 1 : cfg->nproc;
+    const int W = cfg->world_size < 1 ? 1 : cfg->world_size;
+    const int nproc = std::max(cfg->nproc < 1 ? 1 : cfg->nproc, 1);
     if (nproc >= cfg->d) return fail(TTX_EINVAL, "nproc exceeds or equal dimension, cannot proceed");   // lib/dmrgg.f90:114-117
-    if (cfg->world_size > 1) return fail(TTX_EINVAL, "ttx_create: world_size > 1 needs ttx_comm_init (not in this build yet)");
+    if (nproc < W) return fail(TTX_EINVAL, "ttx_create: %d bond groups cannot be spread over %d GPUs", nproc, W);
+    if (nproc > 256) return fail(TTX_EINVAL, "ttx_create: at most 256 bond groups");
+    if (cfg->world_rank < 0 || cfg->world_rank >= W) return fail(TTX_EINVAL, "ttx_create: world_rank out of range");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "ttx_create: no HIP device (the engine has no CPU path)");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(TTX_ENODEV, "ttx_create: device %d not present", cfg->device);
@@ -112,6 +154,7 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     ttx_engine *h = new ttx_engine();
     h->cfg = *cfg;
     h->cfg.nproc = nproc;
+    h->W = W; h->wrank = cfg->world_rank;
     const int d = cfg->d;
     h->d = d; h->RM = cfg->maxrank;
     h->n1.assign(d + 2, 1);
@@ -124,16 +167,18 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     if (cfg->mybonds) h->own.assign(cfg->mybonds, cfg->mybonds + nproc + 1);
     else share(1, d - 1, nproc, h->own);                               // lib/dmrgg.f90:126-130
     for (int g = 0; g < nproc; g++) if (h->own[g + 1] <= h->own[g]) { delete h; return fail(TTX_EINVAL, "mybonds: empty group %d", g); }
-    h->G = nproc; h->g0 = 0;
+    // bond groups are dealt contiguously to the GPUs of the job
+    h->g0 = (int)((long long)nproc * h->wrank / W);
+    h->G = (int)((long long)nproc * (h->wrank + 1) / W) - h->g0;
     h->nbmax = 0;
-    for (int g = 0; g < nproc; g++) h->nbmax = std::max(h->nbmax, h->own[g + 1] - h->own[g]);
+    for (int g = 0; g < nproc; g++) h->nbmax = std::max(h->nbmax, h->own[g + 1] - h->own[g]);   // same launch shape on every GPU
     h->NC = h->nbmax + 1;
     h->mode = (cfg->pivoting == 0) ? 1 : 0;
     h->H = (cfg->pivoting == 0) ? 2 : 2 * cfg->pivoting;
     HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 
     DevProb &P = h->P;
-    P.d = d; P.RM = h->RM; P.NM = NM; P.G = h->G; P.NC = h->NC;
+    P.d = d; P.RM = h->RM; P.NM = NM; P.G = h->G; P.NC = h->NC; P.g0 = h->g0;
     P.fun_id = cfg->fun_id; P.piv = cfg->pivoting; P.npar = cfg->npar; P.nprocs = nproc;
     P.ising_id = (cfg->fun_id == TTX_FUN_ISING) ? (int)cfg->par[2 * cfg->n[0]] : 0;
     P.has_quad = cfg->quadw != nullptr;
@@ -166,31 +211,34 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     A_(dev_alloc(h, &P.L, G * NC * d * RM)); A_(dev_alloc(h, &P.R, G * NC * d * RM));
     A_(dev_alloc(h, &P.r, G * (d + 2))); A_(dev_alloc(h, &P.rr, G * (d + 2))); A_(dev_alloc(h, &P.upd, G * (d + 2))); A_(dev_alloc(h, &P.tape, G * (d + 2) * 4));
     A_(dev_alloc(h, &P.acol, G * RM * NM)); A_(dev_alloc(h, &P.arow, G * RM * NM));
-    A_(dev_alloc(h, &P.Tq, G * NC * RM * RM)); A_(dev_alloc(h, &P.qpart, G * RM * RM));
+    A_(dev_alloc(h, &P.Tq, G * NC * RM * RM));
     A_(dev_alloc(h, &P.ind0, d + 2)); A_(dev_alloc(h, &P.gs, G));
-    A_(dev_alloc(h, &h->d_out, G));
+    // exchange buffers
     P.XD = RM * NM + RM * RM;
-    A_(dev_alloc(h, &P.sendR_h, G * XH)); A_(dev_alloc(h, &P.sendL_h, G * XH));
-    A_(dev_alloc(h, &P.sendR_i, G * (d + 2))); A_(dev_alloc(h, &P.sendL_i, G * (d + 2)));
-    A_(dev_alloc(h, &P.sendR_d, G * P.XD)); A_(dev_alloc(h, &P.sendL_d, G * P.XD));
-    A_(dev_alloc(h, &P.inL_h, G)); A_(dev_alloc(h, &P.inR_h, G)); A_(dev_alloc(h, &P.inL_i, G)); A_(dev_alloc(h, &P.inR_i, G));
-    A_(dev_alloc(h, &P.inL_d, G)); A_(dev_alloc(h, &P.inR_d, G));
-    A_(dev_alloc(h, &P.red, G * 4)); A_(dev_alloc(h, &P.qdims, G * 2)); A_(dev_alloc(h, &P.qwork, (G + 2) * RM * RM));
-    {   // neighbour message routing between groups of this GPU
-        std::vector<int *> lh(G, nullptr), rh(G, nullptr), li(G, nullptr), ri(G, nullptr);
-        std::vector<double *> ld(G, nullptr), rd(G, nullptr);
+    P.IOFF = (sizeof(int) * (XH + d + 2) + 15) & ~(size_t)15;
+    P.MSZ = (P.IOFF + sizeof(double) * P.XD + 15) & ~(size_t)15;
+    A_(dev_alloc(h, &P.msgR, G * P.MSZ)); A_(dev_alloc(h, &P.msgL, G * P.MSZ));
+    A_(dev_alloc(h, &h->recvL, P.MSZ)); A_(dev_alloc(h, &h->recvR, P.MSZ));
+    A_(dev_alloc(h, &P.inL, G)); A_(dev_alloc(h, &P.inR, G));
+    A_(dev_alloc(h, &P.red, G * 4)); A_(dev_alloc(h, &P.redsend, 4));
+    h->QB = (size_t)nproc * RM * RM + 2 * nproc;
+    h->SB = SUM_HDR + nproc + 5 * (size_t)(d + 1);
+    A_(dev_alloc(h, &P.qsend, h->QB)); A_(dev_alloc(h, &P.qwork, ((size_t)nproc + 2) * RM * RM)); A_(dev_alloc(h, &P.sumsend, h->SB));
+    if (W > 1) { A_(dev_alloc(h, &P.redrecv, 4)); A_(dev_alloc(h, &P.qall, h->QB)); A_(dev_alloc(h, &P.sumrecv, h->SB)); }
+    else { P.redrecv = P.redsend; P.qall = P.qsend; P.sumrecv = P.sumsend; }     // one GPU: results alias the inputs
+    {   // message routing: neighbour on this GPU -> its send buffer; on another GPU -> the receive buffer
+        std::vector<char *> il(G, nullptr), ir(G, nullptr);
         for (size_t g = 0; g < G; g++) {
-            if (g > 0) { lh[g] = P.sendR_h + (g - 1) * XH; li[g] = P.sendR_i + (g - 1) * (d + 2); ld[g] = P.sendR_d + (g - 1) * P.XD; }
-            if (g + 1 < G) { rh[g] = P.sendL_h + (g + 1) * XH; ri[g] = P.sendL_i + (g + 1) * (d + 2); rd[g] = P.sendL_d + (g + 1) * P.XD; }
+            if (g > 0) il[g] = P.msgR + (g - 1) * P.MSZ; else if (h->g0 > 0) il[g] = h->recvL;
+            if (g + 1 < G) ir[g] = P.msgL + (g + 1) * P.MSZ; else if (h->g0 + (int)G < nproc) ir[g] = h->recvR;
         }
-        HIPCHECK(hipMemcpy(P.inL_h, lh.data(), sizeof(int *) * G, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(P.inR_h, rh.data(), sizeof(int *) * G, hipMemcpyHostToDevice));
-        HIPCHECK(hipMemcpy(P.inL_i, li.data(), sizeof(int *) * G, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(P.inR_i, ri.data(), sizeof(int *) * G, hipMemcpyHostToDevice));
-        HIPCHECK(hipMemcpy(P.inL_d, ld.data(), sizeof(double *) * G, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(P.inR_d, rd.data(), sizeof(double *) * G, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(P.inL, il.data(), sizeof(char *) * G, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(P.inR, ir.data(), sizeof(char *) * G, hipMemcpyHostToDevice));
     }
 #undef A_
-    HIPCHECK(hipHostMalloc((void **)&h->h_out, sizeof(HostOut) * G));
-    HIPCHECK(hipHostMalloc((void **)&h->h_r, sizeof(int32_t) * G * (d + 2)));
-    HIPCHECK(hipHostMalloc((void **)&h->h_tape, sizeof(int32_t) * G * (d + 2) * 4));
+    HIPCHECK(hipHostMalloc((void **)&h->h_sum, sizeof(double) * h->SB));
+    HIPCHECK(hipHostMalloc((void **)&h->h_msg, 4 * P.MSZ));
+    HIPCHECK(hipHostMalloc((void **)&h->h_tmp, sizeof(double) * std::max(h->QB, h->SB)));
     h->lds_par = sizeof(double) * (cfg->npar + 2);
     h->lds_half = sizeof(double) * (cfg->npar + RM + 2) + sizeof(int) * (d + 4) + sizeof(short) * ((size_t)d * RM + 8);
     {
@@ -206,17 +254,82 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
 extern "C" void ttx_destroy(ttx_engine *h)
 {
     if (!h) return;
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     for (void *p : h->allocs) (void)hipFree(p);
-    if (h->h_out) (void)hipHostFree(h->h_out);
-    if (h->h_r) (void)hipHostFree(h->h_r);
-    if (h->h_tape) (void)hipHostFree(h->h_tape);
+    if (h->h_sum) (void)hipHostFree(h->h_sum);
+    if (h->h_msg) (void)hipHostFree(h->h_msg);
+    if (h->h_tmp) (void)hipHostFree(h->h_tmp);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
-extern "C" int ttx_comm_unique_id(uint8_t id[128]) { (void)id; return fail(TTX_ESTATE, "ttx_comm_unique_id: RCCL transport not built yet"); }
-extern "C" int ttx_comm_init(ttx_engine *h, const uint8_t id[128]) { (void)h; (void)id; return fail(TTX_ESTATE, "ttx_comm_init: RCCL transport not built yet"); }
+// ---- transports between the GPUs of one job ---------------------------------------------------------
+extern "C" int ttx_comm_unique_id(uint8_t id[128])
+{
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId u;
+    NCCLCHECK(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, 128);
+    return TTX_OK;
+}
+extern "C" int ttx_comm_init(ttx_engine *h, const uint8_t id[128])
+{
+    if (!h) return fail(TTX_EINVAL, "ttx_comm_init: null handle");
+    if (h->W == 1) return TTX_OK;
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, 128);
+    NCCLCHECK(g_rccl.CommInitRank(&h->comm, h->W, u, h->wrank));
+    return TTX_OK;
+}
+extern "C" int ttx_set_transport(ttx_engine *h, const ttx_transport *t)
+{
+    if (!h || !t || !t->sendrecv || !t->allreduce) return fail(TTX_EINVAL, "ttx_set_transport: null argument");
+    h->cb = *t; h->have_cb = true;
+    return TTX_OK;
+}
+
+// messages of the boundary groups to the neighbouring GPUs (device buffers; after k_exch_pack)
+static int xfer_neighbours(ttx_engine *h)
+{
+    if (h->W == 1) return TTX_OK;
+    DevProb &P = h->P;
+    const int left = (h->g0 > 0) ? h->wrank - 1 : -1, right = (h->g0 + h->G < h->cfg.nproc) ? h->wrank + 1 : -1;
+    char *outR = P.msgR + (size_t)(h->G - 1) * P.MSZ, *outL = P.msgL;
+    if (h->comm) {
+        NCCLCHECK(g_rccl.GroupStart());
+        if (right >= 0) { NCCLCHECK(g_rccl.Send(outR, P.MSZ, ncclChar, right, h->comm, h->stream)); NCCLCHECK(g_rccl.Recv(h->recvR, P.MSZ, ncclChar, right, h->comm, h->stream)); }
+        if (left >= 0) { NCCLCHECK(g_rccl.Send(outL, P.MSZ, ncclChar, left, h->comm, h->stream)); NCCLCHECK(g_rccl.Recv(h->recvL, P.MSZ, ncclChar, left, h->comm, h->stream)); }
+        NCCLCHECK(g_rccl.GroupEnd());
+        return TTX_OK;
+    }
+    if (!h->have_cb) return fail(TTX_ESTATE, "world_size > 1 but neither ttx_comm_init nor ttx_set_transport was called");
+    char *sR = h->h_msg, *sL = h->h_msg + P.MSZ, *rL = h->h_msg + 2 * P.MSZ, *rR = h->h_msg + 3 * P.MSZ;
+    if (right >= 0) HIPCHECK(hipMemcpyAsync(sR, outR, P.MSZ, hipMemcpyDeviceToHost, h->stream));
+    if (left >= 0) HIPCHECK(hipMemcpyAsync(sL, outL, P.MSZ, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->cb.sendrecv(h->cb.ctx, right, sR, (int64_t)P.MSZ, left, rL, (int64_t)P.MSZ)) return fail(TTX_EHIP, "transport sendrecv (right-going) failed");
+    if (h->cb.sendrecv(h->cb.ctx, left, sL, (int64_t)P.MSZ, right, rR, (int64_t)P.MSZ)) return fail(TTX_EHIP, "transport sendrecv (left-going) failed");
+    if (left >= 0) HIPCHECK(hipMemcpyAsync(h->recvL, rL, P.MSZ, hipMemcpyHostToDevice, h->stream));
+    if (right >= 0) HIPCHECK(hipMemcpyAsync(h->recvR, rR, P.MSZ, hipMemcpyHostToDevice, h->stream));
+    return TTX_OK;
+}
+// all-reduce of `count` doubles from device buffer src into device buffer dst; op 0 = sum, 1 = max
+static int allreduce_dev(ttx_engine *h, const double *src, double *dst, size_t count, int op)
+{
+    if (h->W == 1) return TTX_OK;                       // dst aliases src
+    if (h->comm) { NCCLCHECK(g_rccl.AllReduce(src, dst, count, ncclDouble, op ? ncclMax : ncclSum, h->comm, h->stream)); return TTX_OK; }
+    if (!h->have_cb) return fail(TTX_ESTATE, "world_size > 1 but neither ttx_comm_init nor ttx_set_transport was called");
+    HIPCHECK(hipMemcpyAsync(h->h_tmp, src, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->cb.allreduce(h->cb.ctx, h->h_tmp, (int64_t)count, op)) return fail(TTX_EHIP, "transport allreduce failed");
+    HIPCHECK(hipMemcpyAsync(dst, h->h_tmp, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
+    return TTX_OK;
+}
 
 // ---- launch helpers -------------------------------------------------------------------------------
 static hipEvent_t ev_get(ttx_engine *h)
@@ -224,35 +337,22 @@ static hipEvent_t ev_get(ttx_engine *h)
     if (!h->evpool.empty()) { hipEvent_t e = h->evpool.back(); h->evpool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
+// brackets `n` consecutive launches of one kind with a single HIP event pair on the engine's stream
 struct KScope {
-    ttx_engine *h; int kind; hipEvent_t a = nullptr, b = nullptr;
-    KScope(ttx_engine *h_, int kind_) : h(h_), kind(kind_) { if (h->profile) { a = ev_get(h); b = ev_get(h); (void)hipEventRecord(a, h->stream); } }
-    ~KScope() { if (h->profile) { (void)hipEventRecord(b, h->stream); h->evs.push_back({kind, a, b}); } else h->k_launches[kind]++; }
+    ttx_engine *h; int kind, n; hipEvent_t a = nullptr, b = nullptr;
+    KScope(ttx_engine *h_, int kind_, int n_ = 1) : h(h_), kind(kind_), n(n_) { if (h->profile) { a = ev_get(h); b = ev_get(h); (void)hipEventRecord(a, h->stream); } }
+    ~KScope() { if (h->profile) { (void)hipEventRecord(b, h->stream); h->evs.push_back({kind, n, a, b}); } else h->k_launches[kind] += n; }
 };
 static void ev_collect(ttx_engine *h)
 {
     for (auto &e : h->evs) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e.a, e.b);
-        h->k_ms[e.kind] += ms; h->k_launches[e.kind]++;
+        h->k_ms[e.kind] += ms; h->k_launches[e.kind] += e.n;
         h->evpool.push_back(e.a); h->evpool.push_back(e.b);
     }
     h->evs.clear();
 }
-
-__global__ void k_collect(DevProb P, HostOut *out)
-{
-    int g = blockIdx.x;
-    if (threadIdx.x) return;
-    const GroupState &gs = P.gs[g];
-    HostOut o;
-    o.amax = gs.amax; o.pivotmax = gs.pivotmax; o.pivotmin = gs.pivotmin; o.val = gs.val; o.initval = gs.initval;
-    o.neval = gs.neval; o.bytes_half = gs.bytes_half; o.n_resid = gs.n_resid;
-    out[g] = o;
-}
-
-template <int FUN>
-static int run_impl(ttx_engine *h);
 
 static double erank_host(const ttx_engine *h, const int32_t *r)
 {
@@ -290,7 +390,8 @@ static std::string fmt_e(int w, int dgt, double v)
 
 static void print_line(const ttx_engine *h, const ttx_sweep_rec &r, double val_prev)
 {
-    // lib/dmrgg.f90:971-1008
+    // lib/dmrgg.f90:971-1008 (printed by rank 0 only)
+    if (h->wrank != 0) return;
     const char *sd = r.dir == 0 ? "::" : r.dir == 1 ? ">>" : "<<";
     printf("%3d%2s rank%5.1f time: %s n_evals: %10lld", r.it, sd, r.erank, fmt_e(9, 3, r.seconds).c_str(), (long long)r.neval);
     if (h->P.has_quad) {
@@ -302,24 +403,32 @@ static void print_line(const ttx_engine *h, const ttx_sweep_rec &r, double val_p
     fflush(stdout);
 }
 
+// job-wide summary of the sweep -> h->h_sum (one all-reduce, one stream synchronisation)
 static int readback(ttx_engine *h)
 {
-    const size_t G = h->G, d = h->d;
-    hipLaunchKernelGGL(k_collect, dim3(h->G), dim3(64), 0, h->stream, h->P, h->d_out);
-    HIPCHECK(hipMemcpyAsync(h->h_out, h->d_out, sizeof(HostOut) * G, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipMemcpyAsync(h->h_r, h->P.r, sizeof(int32_t) * G * (d + 2), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipMemcpyAsync(h->h_tape, h->P.tape, sizeof(int32_t) * G * (d + 2) * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(k_collect, dim3(1), dim3(64), 0, h->stream, h->P);
+    if (h->W > 1 && !h->comm) {
+        // host-callback transport: reduce on the host copy directly
+        if (!h->have_cb) return fail(TTX_ESTATE, "world_size > 1 but neither ttx_comm_init nor ttx_set_transport was called");
+        HIPCHECK(hipMemcpyAsync(h->h_sum, h->P.sumsend, sizeof(double) * h->SB, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        if (h->cb.allreduce(h->cb.ctx, h->h_sum, (int64_t)h->SB, 0)) return fail(TTX_EHIP, "transport allreduce failed");
+    } else {
+        int rc = allreduce_dev(h, h->P.sumsend, h->P.sumrecv, h->SB, 0);
+        if (rc) return rc;
+        HIPCHECK(hipMemcpyAsync(h->h_sum, h->P.sumrecv, sizeof(double) * h->SB, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
     if (h->profile) ev_collect(h);
     return TTX_OK;
 }
+static inline const double *sum_bond(const ttx_engine *h, int p) { return h->h_sum + SUM_HDR + h->cfg.nproc + 5 * (size_t)p; }
 
 // bond ranks as the owning groups hold them (valid after readback)
 static std::vector<int32_t> global_ranks(const ttx_engine *h)
 {
     std::vector<int32_t> r(h->d + 1, 1);
-    for (int g = 0; g < h->G; g++)
-        for (int p = h->own[h->g0 + g]; p < h->own[h->g0 + g + 1]; p++) r[p] = h->h_r[(size_t)g * (h->d + 2) + p];
+    for (int p = 1; p < h->d; p++) r[p] = (int32_t)sum_bond(h, p)[0];
     return r;
 }
 // The reference prints erank(arg) of rank 0, whose knowledge of a bond owned by rank g lags g-1 sweeps behind
@@ -330,8 +439,7 @@ static std::vector<int32_t> rank0_view(ttx_engine *h, int it)
     const int d = h->d;
     if (it == 0) { h->updhist.clear(); return std::vector<int32_t>(d + 1, 1); }
     std::vector<uint8_t> u(d + 1, 0);
-    for (int g = 0; g < h->G; g++)
-        for (int p = h->own[h->g0 + g]; p < h->own[h->g0 + g + 1]; p++) u[p] = h->h_tape[((size_t)g * (d + 2) + p) * 4] > 0;
+    for (int p = 1; p < d; p++) u[p] = sum_bond(h, p)[1] > 0.0;
     h->updhist.push_back(u);
     std::vector<int32_t> r(d + 1, 1);
     for (int g = 0; g < h->cfg.nproc; g++) {
@@ -340,6 +448,21 @@ static std::vector<int32_t> rank0_view(ttx_engine *h, int it)
             for (int t = 1; t <= upto; t++) r[p] += h->updhist[t - 1][p];
     }
     return r;
+}
+
+// quadrature of the current cores: per-core matrices, per-group chains, gather over GPUs, tree
+static int launch_quad(ttx_engine *h, int mode, const double *w)
+{
+    DevProb &P = h->P;
+    const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
+    hipLaunchKernelGGL(k_quad_build, dim3(h->NC, h->G), dim3(256), lds_q, h->stream, P, mode, w);
+    hipLaunchKernelGGL(k_quad_chain, dim3(h->G), dim3(256), 2 * lds_q, h->stream, P);
+    if (h->cfg.nproc > 1) {
+        int rc = allreduce_dev(h, P.qsend, P.qall, h->QB, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_quad_tree, dim3(1), dim3(256), 0, h->stream, P);
+    }
+    return TTX_OK;
 }
 
 template <int FUN>
@@ -352,6 +475,7 @@ static int run_impl(ttx_engine *h)
     const int d = h->d, G = h->G, nproc = h->cfg.nproc;
     hipStream_t st = h->stream;
     h->recs.clear(); h->tapes.clear();
+    int rc;
 
     // ---- reset state (lib/dmrgg.f90:96-100, 141-148, 279-288) ----
     {
@@ -364,6 +488,8 @@ static int run_impl(ttx_engine *h)
         HIPCHECK(hipMemcpyAsync(P.rr, ones.data(), sizeof(int32_t) * ones.size(), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(P.tape, m1.data(), sizeof(int32_t) * m1.size(), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemsetAsync(P.upd, 0, sizeof(int32_t) * (size_t)G * (d + 2), st));
+        HIPCHECK(hipMemsetAsync(P.sumsend, 0, sizeof(double) * h->SB, st));
+        HIPCHECK(hipMemsetAsync(P.qsend, 0, sizeof(double) * h->QB, st));
         HIPCHECK(hipStreamSynchronize(st));   // host vectors go out of scope
     }
     // ---- initial cross (:151-301) ----
@@ -371,24 +497,22 @@ static int run_impl(ttx_engine *h)
     int nn = h->n1[1];
     for (int k = 2; k <= d; k++) nn = std::min(nn, h->n1[k]);
     {
-        KScope ks(h, TTX_K_OTHER);
+        KScope ks(h, TTX_K_OTHER, 4);
         hipLaunchKernelGGL(k_init_samples<FUN>, dim3(G), dim3(256), h->lds_par, st, P, snum, nn, 0, 0);
+        hipLaunchKernelGGL(k_init_fibers<FUN>, dim3(h->NC, G), dim3(256), h->lds_par, st, P);
+        hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(k_init_final, dim3(G), dim3(64), 0, st, P);
     }
-    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_init_fibers<FUN>, dim3(h->NC, G), dim3(256), h->lds_par, st, P); }
-    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), 0, st, P); }
-    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_init_final, dim3(G), dim3(64), 0, st, P); }
-    int rc = readback(h);
-    if (rc) return rc;
+    if ((rc = readback(h))) return rc;
     HIPCHECK(hipGetLastError());
     double val = 1.0, val_prev = 1.0;
-    for (int g = 0; g < G; g++) val = (g == 0) ? h->h_out[g].initval : val * h->h_out[g].initval;   // :259-267 PROD
+    for (int g = 0; g < nproc; g++) val = (g == 0) ? h->h_sum[SUM_HDR + g] : val * h->h_sum[SUM_HDR + g];   // :259-267 PROD
     if (!P.has_quad) val = 0.0;
     val_prev = val;
-    auto total_neval = [&]() { long long s = 0; for (int g = 0; g < G; g++) s += h->h_out[g].neval; return s; };
     {
         ttx_sweep_rec r{};
-        r.it = 0; r.dir = 0; r.erank = erank_host(h, rank0_view(h, 0).data()); r.neval = total_neval(); r.val = val;
-        r.amax = h->h_out[0].amax; r.pivotmax = -1; r.pivotmin = -1; r.seconds = since();
+        r.it = 0; r.dir = 0; r.erank = erank_host(h, rank0_view(h, 0).data()); r.neval = (int64_t)h->h_sum[SUM_NEVAL]; r.val = val;
+        r.amax = h->h_sum[SUM_AMAX]; r.pivotmax = -1; r.pivotmin = -1; r.seconds = since();
         h->recs.push_back(r);
         if (h->cfg.verbose) print_line(h, r, val_prev);
     }
@@ -398,69 +522,70 @@ static int run_impl(ttx_engine *h)
     bool ready = (it + 1 >= h->cfg.maxrank);
     const int nfb = (h->RM * h->NM + TTX_BLK - 1) / TTX_BLK;
     const size_t lds_acc = sizeof(double) * (h->RM + 2);
-    const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
     while (!ready) {
         it++;
         const int dir = 2 - it % 2;
         for (int pp = 1; pp <= h->nbmax; pp++) {
             { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_batch); }
-            for (int hh = 0; hh < h->H; hh++) {
-                KScope ks(h, TTX_K_HALFSTEP);
-                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode);
+            {
+                KScope ks(h, TTX_K_HALFSTEP, h->H);
+                for (int hh = 0; hh < h->H; hh++)
+                    hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode);
             }
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }
         {   // per-sweep exchange between bond groups (:763-961)
-            KScope ks(h, TTX_K_EXCHANGE);
+            KScope ks(h, TTX_K_EXCHANGE, nproc > 1 ? 5 : 3);
             hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
-            hipLaunchKernelGGL(k_exch_max, dim3(1), dim3(64), 0, st, P, G);
-            if (G > 1) {
+            hipLaunchKernelGGL(k_exch_localmax, dim3(1), dim3(64), 0, st, P);
+            if ((rc = xfer_neighbours(h))) return rc;
+            if ((rc = allreduce_dev(h, P.redsend, P.redrecv, 4, 1))) return rc;
+            hipLaunchKernelGGL(k_exch_max, dim3(1), dim3(64), 0, st, P);
+            if (nproc > 1) {
                 hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
                 hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8), st, P);
             }
         }
         if (P.has_quad) {
-            KScope ks(h, TTX_K_QUAD);
-            hipLaunchKernelGGL(k_quad_build, dim3(h->NC, G), dim3(256), lds_q, st, P, 0, P.quadw);
-            hipLaunchKernelGGL(k_quad_chain, dim3(G), dim3(256), 2 * lds_q, st, P);
-            if (G > 1) hipLaunchKernelGGL(k_quad_tree, dim3(1), dim3(256), 0, st, P, (const double *)P.qpart, (const int *)P.qdims, G, P.qwork);
+            KScope ks(h, TTX_K_QUAD, nproc > 1 ? 3 : 2);
+            if ((rc = launch_quad(h, 0, P.quadw))) return rc;
         }
-        rc = readback(h);
-        if (rc) return rc;
+        if ((rc = readback(h))) return rc;
         HIPCHECK(hipGetLastError());
-        if (P.has_quad) val = h->h_out[0].val;
+        // every GPU ran the same tree on the same gathered matrices: val is identical everywhere
+        if (P.has_quad) val = h->h_sum[SUM_VAL];
         ttx_sweep_rec r{};
-        r.it = it; r.dir = dir; r.erank = erank_host(h, rank0_view(h, it).data()); r.neval = total_neval(); r.val = val;
-        r.amax = h->h_out[0].amax; r.pivotmax = h->h_out[0].pivotmax; r.pivotmin = h->h_out[0].pivotmin; r.seconds = since();
+        r.it = it; r.dir = dir; r.erank = erank_host(h, rank0_view(h, it).data()); r.neval = (int64_t)h->h_sum[SUM_NEVAL]; r.val = val;
+        r.amax = h->h_sum[SUM_AMAX]; r.pivotmax = h->h_sum[SUM_PMAX]; r.pivotmin = h->h_sum[SUM_PMIN]; r.seconds = since();
         h->recs.push_back(r);
         {
             size_t o = h->tapes.size();
             h->tapes.resize(o + (size_t)(d + 1) * 4, -1);
-            for (int g = 0; g < G; g++)
-                for (int p = h->own[h->g0 + g]; p < h->own[h->g0 + g + 1]; p++)
-                    memcpy(&h->tapes[o + (size_t)p * 4], &h->h_tape[((size_t)g * (d + 2) + p) * 4], sizeof(int32_t) * 4);
+            for (int p = 1; p < d; p++) for (int x = 0; x < 4; x++) h->tapes[o + (size_t)p * 4 + x] = (int32_t)sum_bond(h, p)[1 + x];
         }
         if (h->cfg.verbose) print_line(h, r, val_prev);
         val_prev = val;
         ready = ready || (it + 1 >= h->cfg.maxrank);                              // :1011
-        if (h->cfg.accuracy >= 0.0) {                                             // :1012-1019
+        if (h->cfg.accuracy >= 0.0) {                                             // :1012-1019 (rank 0's amax, global pivotmax)
             if (r.pivotmax <= h->cfg.accuracy * r.amax) strike++; else strike = 0;
             ready = ready || (strike >= 3);
         }
     }
     // ---- finalise (:1029): dtt_lua shifts the rightmost inv of every group to its neighbour first ----
-    if (G > 1) {
-        KScope ks(h, TTX_K_EXCHANGE);
-        hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
+    {
+        KScope ks(h, TTX_K_OTHER, 2);
+        if (nproc > 1) {
+            hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
+            if ((rc = xfer_neighbours(h))) return rc;
+            hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
+        }
+        hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), 0, st, P);
     }
-    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), 0, st, P); }
-    { KScope ks(h, TTX_K_OTHER); hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), 0, st, P); }
-    rc = readback(h);
-    if (rc) return rc;
+    if ((rc = readback(h))) return rc;
     HIPCHECK(hipGetLastError());
-    h->neval = total_neval();
-    for (int g = 0; g < G; g++) h->k_bytes[TTX_K_HALFSTEP] += h->h_out[g].bytes_half;
+    h->neval = (int64_t)h->h_sum[SUM_NEVAL];
+    h->k_bytes[TTX_K_HALFSTEP] += h->h_sum[SUM_BYTES];
     h->rfinal = global_ranks(h);
     h->seconds = since();
     h->ran = true;
@@ -543,15 +668,12 @@ extern "C" int ttx_quad(ttx_engine *h, const double *w, double *val)
         HIPCHECK(hipMalloc((void **)&dw, sizeof(double) * wp.size()));
         HIPCHECK(hipMemcpy(dw, wp.data(), sizeof(double) * wp.size(), hipMemcpyHostToDevice));
     }
-    const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
-    hipLaunchKernelGGL(k_quad_build, dim3(h->NC, h->G), dim3(256), lds_q, h->stream, h->P, 1, (const double *)dw);
-    hipLaunchKernelGGL(k_quad_chain, dim3(h->G), dim3(256), 2 * lds_q, h->stream, h->P);
-    if (h->G > 1) hipLaunchKernelGGL(k_quad_tree, dim3(1), dim3(256), 0, h->stream, h->P, (const double *)h->P.qpart, (const int *)h->P.qdims, h->G, h->P.qwork);
-    int rc = readback(h);
+    int rc = launch_quad(h, 1, dw);
+    if (!rc) rc = readback(h);
     if (dw) (void)hipFree(dw);
     if (rc) return rc;
     HIPCHECK(hipGetLastError());
-    *val = h->h_out[0].val;
+    *val = h->h_sum[SUM_VAL];
     return TTX_OK;
 }
 

@@ -742,9 +742,14 @@ __global__ __launch_bounds__(256) void k_quad_chain(DevProb P)
         double *t = prev; prev = next; next = t;
     }
     const int myn = r[lastc];
-    double *out = P.qpart + (size_t)g * RM * RM;
+    const int gg = gs.gglobal;
+    double *out = P.qsend + (size_t)gg * RM * RM;
     for (int x = tid; x < mym * myn; x += blockDim.x) out[(x % mym) + RM * (x / mym)] = prev[(x % mym) + RM * (x / mym)];
-    if (tid == 0) { P.qdims[2 * g] = mym; P.qdims[2 * g + 1] = myn; if (P.nprocs == 1) gs.val = prev[0]; }
+    if (tid == 0) {
+        double *dm = P.qsend + (size_t)P.nprocs * RM * RM;
+        dm[2 * gg] = (double)mym; dm[2 * gg + 1] = (double)myn;
+        if (P.nprocs == 1) gs.val = prev[0];
+    }
 }
 
 // dtt_lua on the raw fibers: luar pass then lual pass (two launches: the second needs the whole core)
@@ -844,7 +849,6 @@ __global__ void k_lottery_only(int npnt, int m, int n, int nz, const int *zcol, 
 // through every rank (which makes far bonds lag by one sweep per hop), the owner ships the FLATTENED
 // multi-index of its new boundary pivot to its direct neighbour -- the only rank that ever evaluates with it.
 // ------------------------------------------------------------------------------------------------
-#define XH 8
 // one block per group: pack both outgoing messages and the group's entry of the MAX all-reduce
 __global__ __launch_bounds__(256) void k_exch_pack(DevProb P)
 {
@@ -858,7 +862,8 @@ __global__ __launch_bounds__(256) void k_exch_pack(DevProb P)
     }
     {   // to the right neighbour: own last bond q = last, boundary core q+1
         const int q = last, u = upd[q];
-        int *hh = P.sendR_h + (size_t)g * XH; int *ix = P.sendR_i + (size_t)g * (m + 2); double *dd = P.sendR_d + (size_t)g * P.XD;
+        char *base = P.msgR + (size_t)g * P.MSZ;
+        int *hh = (int *)base; int *ix = hh + XH; double *dd = (double *)(base + P.IOFF);
         if (tid == 0) { hh[0] = u; hh[1] = r[q]; }
         const int rq = r[q];
         const double *gI = inv_ptr(P, g, q, first);
@@ -874,7 +879,8 @@ __global__ __launch_bounds__(256) void k_exch_pack(DevProb P)
     }
     {   // to the left neighbour: own first bond q = first, boundary core q
         const int q = first, u = upd[q];
-        int *hh = P.sendL_h + (size_t)g * XH; int *ix = P.sendL_i + (size_t)g * (m + 2); double *dd = P.sendL_d + (size_t)g * P.XD;
+        char *base = P.msgL + (size_t)g * P.MSZ;
+        int *hh = (int *)base; int *ix = hh + XH; double *dd = (double *)(base + P.IOFF);
         if (tid == 0) { hh[0] = u; hh[1] = r[q]; }
         if (u) {
             const int rq = r[q];
@@ -888,17 +894,23 @@ __global__ __launch_bounds__(256) void k_exch_pack(DevProb P)
     }
 }
 
-// MAX all-reduce over the groups of this GPU (:861); nred = number of entries in P.red (local groups, or
-// 1 after an RCCL all-reduce has already combined all GPUs into entry 0)
-__global__ void k_exch_max(DevProb P, int nred)
+// MAX all-reduce (:861), stage 1: combine the groups of this GPU into redsend[0..2]
+__global__ void k_exch_localmax(DevProb P)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double a = -1e300, b = -1e300, c = -1e300;
-    for (int g = 0; g < nred; g++) { a = fmax(a, P.red[4 * g]); b = fmax(b, P.red[4 * g + 1]); c = fmax(c, P.red[4 * g + 2]); }
+    for (int g = 0; g < P.G; g++) { a = fmax(a, P.red[4 * g]); b = fmax(b, P.red[4 * g + 1]); c = fmax(c, P.red[4 * g + 2]); }
+    P.redsend[0] = a; P.redsend[1] = b; P.redsend[2] = c; P.redsend[3] = 0.0;
+}
+// stage 2 (after the RCCL all-reduce over GPUs, or directly when there is one GPU): :867-870 and :961
+__global__ void k_exch_max(DevProb P)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double a = P.redrecv[0], b = P.redrecv[1], c = P.redrecv[2];
     for (int g = 0; g < P.G; g++) {
         GroupState &gs = P.gs[g];
-        gs.amax = a; gs.pivotmax = b; gs.pivotmin = (-c == 999e9) ? -1.0 : -c;     // :867-870
-        gs.pivotmax_prev = b;                                                      // :961
+        gs.amax = a; gs.pivotmax = b; gs.pivotmin = (-c == 999e9) ? -1.0 : -c;
+        gs.pivotmax_prev = b;
     }
 }
 
@@ -909,18 +921,18 @@ __global__ __launch_bounds__(256) void k_exch_apply(DevProb P)
     GroupState &gs = P.gs[g];
     const int first = gs.first, last = gs.last;
     int *r = P.r + (size_t)g * (m + 2), *upd = P.upd + (size_t)g * (m + 2);
-    if (P.inL_h[g]) {
+    if (P.inL[g]) {
         const int bl = first - 1;
-        const int *hh = P.inL_h[g], *ix = P.inL_i[g]; const double *dd = P.inL_d[g];
+        const int *hh = (const int *)P.inL[g], *ix = hh + XH; const double *dd = (const double *)(P.inL[g] + P.IOFF);
         const int u = hh[0], rnew = hh[1];
         if (u) { short *Lt = L_ptr(P, g, bl, first); for (int x = tid; x < bl; x += blockDim.x) Lt[(size_t)x * P.RM + (rnew - 1)] = (short)ix[x]; }
         double *gI = inv_ptr(P, g, bl, first);
         for (int x = tid; x < rnew * rnew; x += blockDim.x) gI[x] = dd[(size_t)P.RM * P.NM + x];
         if (tid == 0) { upd[bl] = u; r[bl] = rnew; }
     }
-    if (P.inR_h[g]) {
+    if (P.inR[g]) {
         const int br = last + 1;
-        const int *hh = P.inR_h[g], *ix = P.inR_i[g];
+        const int *hh = (const int *)P.inR[g], *ix = hh + XH;
         const int u = hh[0], rnew = hh[1];
         if (u) { short *Rt = R_ptr(P, g, br, first); for (int x = tid; x < m - br; x += blockDim.x) Rt[(size_t)x * P.RM + (rnew - 1)] = (short)ix[x]; }
         if (tid == 0) { upd[br] = u; r[br] = rnew; }
@@ -943,9 +955,9 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
     short *row = (short *)(dyn + P.npar);      // one full multi-index (m shorts) for the corner evaluation
     if ((int)blockIdx.x < P.NM) {
         const int k = blockIdx.x, p = last, br = last + 1;
-        if (!P.inR_h[g] || !upd[br] || k >= P.n[br]) return;
+        if (!P.inR[g] || !upd[br] || k >= P.n[br]) return;
         const int rp = r[p], rrp = rr[p], snew = r[br] - 1, n2 = P.n[br];
-        const double *msg = P.inR_d[g];                              // (rr(p), n(p+1))
+        const double *msg = (const double *)(P.inR[g] + P.IOFF);      // (rr(p), n(p+1))
         double *A = core_ptr(P, P.arg, g, br, first), *W = core_ptr(P, P.row, g, br, first);
         double a = 0.0;
         if (tid < rrp) a = msg[tid + (size_t)rrp * k];
@@ -976,9 +988,9 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
         if (tid < rp) W[k + (size_t)P.NM * snew + P.SW * tid] = xf;
     } else {
         const int j = blockIdx.x - P.NM, p = first, bl = first - 1;
-        if (!P.inL_h[g] || !upd[bl] || j >= P.n[p]) return;
+        if (!P.inL[g] || !upd[bl] || j >= P.n[p]) return;
         const int rp = r[p], rrp = rr[p], inew = r[bl] - 1, n1 = P.n[p];
-        const double *msg = P.inL_d[g];                              // (n(p), rr(p))
+        const double *msg = (const double *)(P.inL[g] + P.IOFF);      // (n(p), rr(p))
         double *A = core_ptr(P, P.arg, g, p, first), *C = core_ptr(P, P.col, g, p, first);
         double y = 0.0;
         if (tid < rrp) y = msg[j + (size_t)n1 * tid];
@@ -1009,14 +1021,18 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
     }
 }
 
-// binary-tree product of the groups' partial quadrature matrices (lib/dmrgg.f90:1355-1405); single block.
-// part[g] is RM x RM padded; dims[2g], dims[2g+1] = (mym, myn) of group g; ng = number of groups
-__global__ __launch_bounds__(256) void k_quad_tree(DevProb P, const double *part, const int *dims, int ng, double *work)
+// binary-tree product of the partial quadrature matrices of ALL groups (lib/dmrgg.f90:1355-1405); single
+// block, run redundantly by every GPU on the all-reduced P.qall so that every rank holds the same value
+__global__ __launch_bounds__(256) void k_quad_tree(DevProb P)
 {
-    const int tid = threadIdx.x, RM = P.RM;
+    const int tid = threadIdx.x, RM = P.RM, ng = P.nprocs;
     __shared__ int mym[256], myn[256];
-    for (int g = tid; g < ng; g += blockDim.x) { mym[g] = dims[2 * g]; myn[g] = dims[2 * g + 1]; }
-    for (int x = tid; x < ng * RM * RM; x += blockDim.x) work[x] = part[x];
+    const double *part = P.qall, *dims = P.qall + (size_t)ng * RM * RM;
+    double *work = P.qwork;
+    for (int g = tid; g < ng; g += blockDim.x) { mym[g] = (int)dims[2 * g]; myn[g] = (int)dims[2 * g + 1]; }
+    __syncthreads();
+    for (int g = 0; g < ng; g++)
+        for (int x = tid; x < mym[g] * myn[g]; x += blockDim.x) work[(size_t)g * RM * RM + (x % mym[g]) + RM * (x / mym[g])] = part[(size_t)g * RM * RM + (x % mym[g]) + RM * (x / mym[g])];
     __syncthreads();
     double *tmp = work + (size_t)ng * RM * RM;
     for (int q = 1; q < ng; q *= 2) {
@@ -1038,5 +1054,27 @@ __global__ __launch_bounds__(256) void k_quad_tree(DevProb P, const double *part
             __syncthreads();
         }
     }
-    if (tid == 0) P.gs[0].val = work[0];
+    if (tid == 0) for (int g = 0; g < P.G; g++) P.gs[g].val = work[0];
+}
+
+// per-sweep summary of this GPU in the job-wide layout (slots of other GPUs stay zero; SUM all-reduce)
+__global__ void k_collect(DevProb P)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int m = P.d;
+    double *o = P.sumsend;
+    double nev = 0.0, by = 0.0, nr = 0.0;
+    for (int g = 0; g < P.G; g++) {
+        const GroupState &gs = P.gs[g];
+        nev += (double)gs.neval; by += gs.bytes_half; nr += (double)gs.n_resid;
+        o[SUM_HDR + gs.gglobal] = gs.initval;
+        if (gs.gglobal == 0) { o[SUM_AMAX] = gs.amax; o[SUM_PMAX] = gs.pivotmax; o[SUM_PMIN] = gs.pivotmin; }
+        const int *r = P.r + (size_t)g * (m + 2), *tp = P.tape + (size_t)g * (m + 2) * 4;
+        for (int p = gs.first; p <= gs.last; p++) {
+            double *e = o + SUM_HDR + P.nprocs + 5 * p;
+            e[0] = (double)r[p]; e[1] = (double)tp[4 * p]; e[2] = (double)tp[4 * p + 1]; e[3] = (double)tp[4 * p + 2]; e[4] = (double)tp[4 * p + 3];
+        }
+    }
+    o[SUM_NEVAL] = nev; o[SUM_BYTES] = by; o[SUM_NRESID] = nr;
+    if (P.g0 == 0) o[SUM_VAL] = P.gs[0].val;     // identical on every GPU; contributed once
 }

@@ -34,6 +34,14 @@ class _Config(ctypes.Structure):
                 ("world_rank", c_int32), ("world_size", c_int32), ("verbose", c_int32), ("use_graph", c_int32)]
 
 
+_SENDRECV = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, ctypes.c_int, c_void_p, c_int64, ctypes.c_int, c_void_p, c_int64)
+_ALLREDUCE = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, POINTER(c_double), c_int64, ctypes.c_int)
+
+
+class _Transport(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p), ("sendrecv", _SENDRECV), ("allreduce", _ALLREDUCE)]
+
+
 class SweepRec(ctypes.Structure):
     _fields_ = [("it", c_int32), ("dir", c_int32), ("erank", c_double), ("neval", c_int64), ("val", c_double),
                 ("amax", c_double), ("pivotmax", c_double), ("pivotmin", c_double), ("seconds", c_double)]
@@ -59,6 +67,7 @@ def load_library():
     L.ttx_destroy.restype = None
     L.ttx_comm_unique_id.argtypes = [POINTER(c_uint8)]
     L.ttx_comm_init.argtypes = [c_void_p, POINTER(c_uint8)]
+    L.ttx_set_transport.argtypes = [c_void_p, POINTER(_Transport)]
     L.ttx_run.argtypes = [c_void_p]
     L.ttx_num_sweeps.argtypes = [c_void_p]
     L.ttx_get_sweeps.argtypes = [c_void_p, POINTER(SweepRec), ctypes.c_int]
@@ -102,7 +111,7 @@ class TTCross:
     sweep state).  n: mode sizes arg%n(1:d); quad: list/array of per-mode weight vectors (rank-1 TT)."""
 
     def __init__(self, n, fun_id, par, maxrank, pivoting=3, accuracy=None, quad=None, tru=None, aux=None,
-                 nproc=1, mybonds=None, device=0, verbose=False, use_graph=False):
+                 nproc=1, mybonds=None, device=0, verbose=False, use_graph=False, world_rank=0, world_size=1):
         L = load_library()
         self._n = np.ascontiguousarray(n, dtype=np.int32)
         self.d = int(self._n.size)
@@ -127,7 +136,8 @@ class TTCross:
         c.nproc = int(nproc)
         c.mybonds = _ip(self._mybonds)
         c.device = int(device)
-        c.world_rank, c.world_size = 0, 1
+        c.world_rank, c.world_size = int(world_rank), int(world_size)
+        self.world_rank, self.world_size = int(world_rank), int(world_size)
         c.verbose = 1 if verbose else 0
         c.use_graph = 1 if use_graph else 0
         self._h = c_void_p()
@@ -139,6 +149,58 @@ class TTCross:
             self._h = None
 
     __del__ = close
+
+    # ---- multi-GPU bootstrap (replaces mpi_init of the drivers) ---------------------------------------
+    def comm_init(self, dist):
+        """RCCL transport: rank 0 creates the unique id, torch.distributed broadcasts it, every rank joins."""
+        import torch
+        L = load_library()
+        buf = (c_uint8 * 128)()
+        if self.world_rank == 0:
+            _check(L.ttx_comm_unique_id(buf))
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        ids = t.cpu().tolist()
+        for i in range(128):
+            buf[i] = ids[i]
+        _check(L.ttx_comm_init(self._h, buf))
+
+    def set_dist_transport(self, dist):
+        """Host-callback transport over torch.distributed CPU tensors (gloo): used where RCCL cannot run
+        (several ranks on one GPU) -- same engine code path, messages staged through pinned host memory."""
+        import torch
+
+        def _t(ptr, nbytes):
+            return torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.uint8)
+
+        def sendrecv(ctx, to, sbuf, ns, frm, rbuf, nr):
+            try:
+                ops = []
+                if to >= 0:
+                    ops.append(dist.P2POp(dist.isend, _t(sbuf, ns), to))
+                if frm >= 0:
+                    ops.append(dist.P2POp(dist.irecv, _t(rbuf, nr), frm))
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("transport sendrecv failed:", e, flush=True)
+                return 1
+
+        def allreduce(ctx, buf, count, op):
+            try:
+                t = torch.frombuffer((ctypes.c_double * count).from_address(ctypes.addressof(buf.contents)), dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("transport allreduce failed:", e, flush=True)
+                return 1
+
+        self._cb = (_SENDRECV(sendrecv), _ALLREDUCE(allreduce))       # keep the thunks alive
+        tr = _Transport(None, self._cb[0], self._cb[1])
+        _check(load_library().ttx_set_transport(self._h, ctypes.byref(tr)))
 
     def set_profile(self, on=True):
         _check(load_library().ttx_set_profile(self._h, 1 if on else 0))
