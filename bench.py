@@ -102,6 +102,7 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        gloo_pg = dist.new_group(backend="gloo")
 
     from ttcross_amd import drivers as D
     from ttcross_amd import engine as E
@@ -113,8 +114,27 @@ def main():
                    nproc=groups, device=local, world_rank=rank, world_size=world) if world > 1 else \
         E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
                   nproc=groups, device=local)
+    transport = "none (single process)"
     if world > 1:
-        tt.comm_init(dist)
+        # data path between GPUs: in-library RCCL point-to-point / all-reduce on the engine's stream; if RCCL cannot
+        # be initialised on ANY rank, all ranks fall back together to the host-staged gloo transport
+        import torch
+        ok = 1
+        try:
+            tt.comm_init(dist)
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] RCCL transport unavailable: {e}", file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            transport = "rccl (ncclSend/ncclRecv + ncclAllReduce over xGMI)"
+        else:
+            tt.close()
+            tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
+                           nproc=groups, device=local, world_rank=rank, world_size=world)
+            tt.set_dist_transport(dist, group=gloo_pg)
+            transport = "gloo host-staged fallback"
 
     def barrier():
         if dist is not None:
@@ -162,7 +182,7 @@ def main():
         "value": neval / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (integrand evaluated on the fly; Gauss-Legendre nodes/weights; flang-compatible lottery RNG stream)",
-        "config": {"workload": desc, "driver": "test_crs_ising " + " ".join(str(x) for x in argv[1:]), "bond_groups": groups,
+        "config": {"workload": desc, "driver": "test_crs_ising " + " ".join(str(x) for x in argv[1:]), "bond_groups": groups, "transport": transport,
                    "neval_per_step": neval // a.steps, "sweeps": nsweeps, "integral": value,
                    "rel_err_vs_analytic": abs(1 - value / s["tru"]) if s["tru"] else None},
         "roofline": {"kernel": "k_halfstep (fiber evaluation + residual + arg-max)", "bound": "hbm", "achieved": achieved,

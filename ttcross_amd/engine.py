@@ -166,7 +166,7 @@ class TTCross:
             buf[i] = ids[i]
         _check(L.ttx_comm_init(self._h, buf))
 
-    def set_dist_transport(self, dist):
+    def set_dist_transport(self, dist, group=None):
         """Host-callback transport over torch.distributed CPU tensors (gloo): used where RCCL cannot run
         (several ranks on one GPU) -- same engine code path, messages staged through pinned host memory."""
         import torch
@@ -178,9 +178,9 @@ class TTCross:
             try:
                 ops = []
                 if to >= 0:
-                    ops.append(dist.P2POp(dist.isend, _t(sbuf, ns), to))
+                    ops.append(dist.P2POp(dist.isend, _t(sbuf, ns), to, group))
                 if frm >= 0:
-                    ops.append(dist.P2POp(dist.irecv, _t(rbuf, nr), frm))
+                    ops.append(dist.P2POp(dist.irecv, _t(rbuf, nr), frm, group))
                 if ops:
                     for w in dist.batch_isend_irecv(ops):
                         w.wait()
@@ -192,7 +192,7 @@ class TTCross:
         def allreduce(ctx, buf, count, op):
             try:
                 t = torch.frombuffer((ctypes.c_double * count).from_address(ctypes.addressof(buf.contents)), dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM, group=group)
                 return 0
             except Exception as e:  # noqa: BLE001
                 print("transport allreduce failed:", e, flush=True)
