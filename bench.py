@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--workload", default="c64", choices=sorted(WORKLOADS))
     ap.add_argument("--groups", type=int, default=0, help="bond groups = MPI ranks of the reference's domain split; default 8 (config 3 of BASELINE.json) at every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (gloo: rehearsal with several ranks on one GPU)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,9 +101,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        gloo_pg = dist.new_group(backend="gloo")
+        if a.backend == "gloo":
+            local = local % max(torch.cuda.device_count(), 1)
+            dist.init_process_group("gloo")
+            gloo_pg = None
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            gloo_pg = dist.new_group(backend="gloo")
 
     from ttcross_amd import drivers as D
     from ttcross_amd import engine as E
@@ -121,11 +127,13 @@ def main():
         import torch
         ok = 1
         try:
+            if a.backend == "gloo":
+                raise RuntimeError("gloo rehearsal: RCCL not attempted")
             tt.comm_init(dist)
         except Exception as e:  # noqa: BLE001
             print(f"[rank {rank}] RCCL transport unavailable: {e}", file=sys.stderr, flush=True)
             ok = 0
-        flag = torch.tensor([ok], device="cuda")
+        flag = torch.tensor([ok], device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             transport = "rccl (ncclSend/ncclRecv + ncclAllReduce over xGMI)"
@@ -138,8 +146,8 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
             import torch
+            dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -154,7 +162,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = tt.quad(s["quad"])
