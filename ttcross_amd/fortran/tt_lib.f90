@@ -1,0 +1,75 @@
+! tt_lib.f90 -- drop-in subset of the reference's ptype_lib / tt_lib (lib/ptype.f90:4-6, lib/tt.f90:16-37,
+! 879-892, 908-916, 1228-1245, 1348-1360): the dtt container the drivers and dtt_dmrgg exchange.
+! Same component names; one extra hidden component carries the device-engine handle.
+module ptype_lib
+ implicit none
+ type,public :: pointd3
+  double precision,dimension(:,:,:),pointer,contiguous :: p=>null()
+ end type
+end module
+
+module tt_lib
+ use iso_c_binding
+ use ptype_lib
+ implicit none
+ integer,parameter :: tt_size=2048
+ type,public :: dtt
+  integer :: l=1
+  integer :: m=0
+  integer :: n(tt_size)=0
+  integer :: q(tt_size)=0
+  integer :: s(tt_size)=0
+  integer :: t=0
+  integer :: r(0:tt_size)=0
+  type(pointd3) :: u(tt_size)
+  type(c_ptr) :: ttx=c_null_ptr      ! engine handle after dtt_dmrgg (not in the reference)
+ end type
+ interface alloc;   module procedure dtt_alloc;   end interface
+ interface dealloc; module procedure dtt_dealloc; end interface
+ interface ones;    module procedure dtt_ones;    end interface
+ interface erank;   module procedure dtt_rank;    end interface
+contains
+ subroutine dtt_alloc(arg)
+  type(dtt),intent(inout) :: arg
+  integer :: i,info
+  if(arg%m.lt.arg%l)return
+  if(arg%l.le.0)then;write(*,*)'dtt_alloc: %l should be > 0';stop;endif
+  if(arg%m.gt.tt_size)then;write(*,*)'dtt_alloc: %m exceeds tt_size, change parameter and recompile!';stop;endif
+  do i=arg%l,arg%m
+   if(associated(arg%u(i)%p))deallocate(arg%u(i)%p)
+   allocate(arg%u(i)%p(arg%r(i-1),arg%n(i),arg%r(i)),stat=info)
+   if(info.ne.0)then;write(*,*)'TT allocate fail: no memory';stop;endif
+  end do
+ end subroutine
+ subroutine dtt_dealloc(arg)
+  use ttx_c, only: ttx_destroy
+  type(dtt),intent(inout) :: arg
+  integer :: i
+  do i=1,tt_size
+   if(associated(arg%u(i)%p))deallocate(arg%u(i)%p)
+  end do
+  if(c_associated(arg%ttx))then; call ttx_destroy(arg%ttx); arg%ttx=c_null_ptr; endif
+ end subroutine
+ subroutine dtt_ones(arg)
+  type(dtt),intent(inout) :: arg
+  integer :: k
+  if(arg%m.lt.arg%l)return
+  arg%r(arg%l-1:arg%m)=1
+  call dtt_alloc(arg)
+  do k=arg%l,arg%m; arg%u(k)%p=1.d0; end do
+ end subroutine
+ double precision function dtt_rank(arg) result(r)
+  type(dtt),intent(in) :: arg
+  integer :: l,m,i,a,b,d
+  l=arg%l;m=arg%m;d=m-l+1
+  if(d.le.0)then;r=-1.d0;return;endif
+  if(d.eq.1)then;r=0.d0;return;endif
+  r=0.d0
+  do i=l,m; r=r+arg%r(i-1)*arg%n(i)*arg%r(i); end do
+  if(r.eq.0.d0)return
+  b=arg%r(l-1)*arg%n(l)+arg%n(m)*arg%r(m)
+  if(d.eq.2)then;r=r/b;return;endif
+  a=sum(arg%n(l+1:m-1))
+  r=(dsqrt(b*b+4.d0*a*r)-b)/(2.d0*a)
+ end function
+end module

@@ -1,0 +1,75 @@
+! ttx_c.f90 -- ISO_C_BINDING view of include/ttx.h (the C-ABI of libttx.so).
+! This is the binding a maintainer of the reference adds to call the MI355X engine from lib/dmrgg.f90.
+module ttx_c
+ use iso_c_binding
+ implicit none
+ integer(c_int32_t),parameter :: TTX_FUN_ISING=1, TTX_FUN_STDNORM=2, TTX_FUN_MVN=3
+ type,bind(C) :: ttx_config
+  integer(c_int32_t) :: d
+  type(c_ptr) :: n
+  integer(c_int32_t) :: fun_id
+  type(c_ptr) :: par
+  integer(c_int32_t) :: npar
+  type(c_ptr) :: aux
+  integer(c_int32_t) :: naux
+  type(c_ptr) :: quadw
+  real(c_double) :: accuracy
+  integer(c_int32_t) :: maxrank
+  integer(c_int32_t) :: pivoting
+  real(c_double) :: tru
+  integer(c_int32_t) :: has_tru
+  integer(c_int32_t) :: nproc
+  type(c_ptr) :: mybonds
+  integer(c_int32_t) :: device
+  integer(c_int32_t) :: world_rank
+  integer(c_int32_t) :: world_size
+  integer(c_int32_t) :: verbose
+  integer(c_int32_t) :: use_graph
+ end type
+ interface
+  function ttx_last_error() bind(C,name='ttx_last_error') result(p)
+   import; type(c_ptr) :: p
+  end function
+  function ttx_create(h,cfg) bind(C,name='ttx_create') result(rc)
+   import; type(c_ptr),intent(out) :: h; type(ttx_config),intent(in) :: cfg; integer(c_int) :: rc
+  end function
+  subroutine ttx_destroy(h) bind(C,name='ttx_destroy')
+   import; type(c_ptr),value :: h
+  end subroutine
+  function ttx_run(h) bind(C,name='ttx_run') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int) :: rc
+  end function
+  function ttx_neval(h) bind(C,name='ttx_neval') result(n)
+   import; type(c_ptr),value :: h; integer(c_int64_t) :: n
+  end function
+  function ttx_get_ranks(h,r) bind(C,name='ttx_get_ranks') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int32_t),intent(out) :: r(*); integer(c_int) :: rc
+  end function
+  function ttx_core_size(h,k) bind(C,name='ttx_core_size') result(n)
+   import; type(c_ptr),value :: h; integer(c_int),value :: k; integer(c_int64_t) :: n
+  end function
+  function ttx_get_core(h,k,buf) bind(C,name='ttx_get_core') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int),value :: k; real(c_double),intent(out) :: buf(*); integer(c_int) :: rc
+  end function
+  function ttx_quad(h,w,val) bind(C,name='ttx_quad') result(rc)
+   import; type(c_ptr),value :: h; type(c_ptr),value :: w; real(c_double),intent(out) :: val; integer(c_int) :: rc
+  end function
+ end interface
+contains
+ subroutine ttx_check(rc,who)
+  ! the reference reports errors as `write(*,*) ...; stop` (e.g. lib/dmrgg.f90:88-91,105-117)
+  integer(c_int),intent(in) :: rc
+  character(len=*),intent(in) :: who
+  character(kind=c_char),pointer :: s(:)
+  integer :: i
+  if(rc.eq.0)return
+  call c_f_pointer(ttx_last_error(),s,[512])
+  write(*,'(a,a)',advance='no') who,': '
+  do i=1,512
+   if(s(i).eq.c_null_char)exit
+   write(*,'(a)',advance='no') s(i)
+  end do
+  write(*,*)
+  stop 1
+ end subroutine
+end module
