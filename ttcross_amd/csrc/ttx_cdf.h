@@ -52,6 +52,16 @@ TTX_HD double ttx_from_units(int64_t v, int be)
     return ttx_bitsd(b);
 }
 
+// floor(N / D) for 0 <= N < 2^54, 0 < D < 2^54 without 64-bit integer division (slow on the device): fp64
+// quotient, then exact correction with integer multiplies
+TTX_HD int64_t ttx_divfloor(int64_t N, int64_t D)
+{
+    int64_t q = (int64_t)((double)N / (double)D);
+    while (q * D > N) q--;
+    while ((q + 1) * D <= N) q++;
+    return q;
+}
+
 // segments covering k = 1..K of a_k = fl(a_{k-1} + c), a_0 = 0, c = 1.0/K; returns their number
 TTX_HD int ttx_cdf_build(int K, ttx_cdfseg *seg)
 {
@@ -72,7 +82,7 @@ TTX_HD int ttx_cdf_build(int K, ttx_cdfseg *seg)
             int64_t Z = ttx_units(a, xe), D = Z - ttx_units(am1, xe);
             const int64_t B = (int64_t)1 << 53;  // 2^(e+1) in units of u = 2^(e-52)
             if (D > 0) {
-                int64_t tmax = (B - Z - 1) / D;  // number of t >= 1 with Z + t*D < B
+                int64_t tmax = ttx_divfloor(B - Z - 1, D);  // number of t >= 1 with Z + t*D < B
                 if (tmax > (int64_t)(K - k)) tmax = K - k;
                 if (tmax > 0) {
                     seg[ns].a0 = ttx_from_units(Z + D, xe);
@@ -100,7 +110,7 @@ TTX_HD int ttx_cdf_kmax(const ttx_cdfseg *seg, int ns, double y)
     int be = ttx_bexp(sg.a0);
     int64_t A = ttx_units(y, be) - ttx_units(sg.a0, be);   // y in [a0, alast): same binade, exact
     int64_t D = ttx_units(sg.delta, be);
-    return sg.k0 + (int)(A / D);
+    return sg.k0 + (int)ttx_divfloor(A, D);
 }
 
 // 1-based position of the kth (1-based) non-zero weight, given the ascending distinct 1-based zero positions:
@@ -118,6 +128,27 @@ TTX_HD int ttx_lottery_index(const ttx_cdfseg *seg, int ns, int K, int m, const 
     int kmax = ttx_cdf_kmax(seg, ns, y);
     if (kmax >= K) return m;
     return ttx_select_nonzero(kmax + 1, zeros, nz);
+}
+
+// minstd power 48271^e mod (2^31-1)
+TTX_HD uint64_t ttx_minstd_pow(uint64_t e)
+{
+    uint64_t base = 48271ULL, w = 1;
+    // (mulmod31 is declared below; forward use is fine inside the header's single translation unit)
+    while (e) {
+        if (e & 1) { uint64_t x = w * base; x = (x & 2147483647ULL) + (x >> 31); x = (x & 2147483647ULL) + (x >> 31); w = (x >= 2147483647ULL) ? x - 2147483647ULL : x; }
+        uint64_t y = base * base; y = (y & 2147483647ULL) + (y >> 31); y = (y & 2147483647ULL) + (y >> 31); base = (y >= 2147483647ULL) ? y - 2147483647ULL : y;
+        e >>= 1;
+    }
+    return w;
+}
+// the double made from the generator word w1 = 48271^(2k+1) (and its successor), as ttx_flang_draw(k)
+TTX_HD double ttx_flang_from_word(uint64_t w1)
+{
+    uint64_t x = w1 * 48271ULL; x = (x & 2147483647ULL) + (x >> 31); x = (x & 2147483647ULL) + (x >> 31);
+    uint64_t w2 = (x >= 2147483647ULL) ? x - 2147483647ULL : x;
+    uint64_t f = ((w1 << 30) | ((w2 - 1) & ((1ULL << 30) - 1))) >> 7;
+    return (double)f * 5.5511151231257827e-17;
 }
 
 // flang run-time random_number (unseeded): minstd 48271 mod 2^31-1 from seed 1, two words per double

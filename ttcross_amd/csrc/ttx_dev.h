@@ -17,6 +17,8 @@
 //        reference's nested walk dmrgg_fun (lib/dmrgg.f90:1062-1075) by independent, coalesced int16 loads.
 #pragma once
 #include <stdint.h>
+#include "ttx_cdf.h"
+#define TTX_TABSEG 64
 
 #define TTX_MAXH 24        // half-step state slots (2*piv+2 <= TTX_MAXH)
 #define TTX_MAXPART 512    // partial arg-max records per half-step (blocks per fiber)
@@ -59,6 +61,9 @@ struct GroupState {
     double initval;        // initial-cross value factor of this group
     double bytes_half;     // algorithmic bytes moved by the half-step kernel, for the roofline
     long long n_resid;     // half-steps that computed a residual
+#ifdef TTX_STAMPS
+    long long stamp[2][16]; long long nstamp[2];   // debug build: accumulated wall_clock64 deltas per phase
+#endif
     StepState S[TTX_MAXH];
     Partial Pt[2][TTX_MAXPART];
 };
@@ -98,5 +103,8 @@ struct DevProb {
     double *qwork;                 // [(nprocs+2)*RM*RM] scratch of the quadrature tree
     double *sumsend, *sumrecv;     // per-sweep job summary (SUM all-reduce): see SUM_* offsets
     int g0;                        // global index of local group 0
+    const ttx_cdfseg *cdf_tab;     // [cdf_kmax+1][TTX_TABSEG] lottery CDF segments for every K (nullptr: build in-kernel)
+    const int *cdf_ns;             // [cdf_kmax+1]
+    int cdf_kmax;
     GroupState *gs;            // [G]
 };

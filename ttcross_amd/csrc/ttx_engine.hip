@@ -101,7 +101,7 @@ struct ttx_engine {
     int64_t k_launches[TTX_K_NKINDS] = {0};
     double k_ms[TTX_K_NKINDS] = {0}, k_bytes[TTX_K_NKINDS] = {0};
     size_t lds_half = 0, lds_lot = 0, lds_par = 0;
-    int lot_batch = 1;
+    int lot_batch = 1, half_vals = 0;
 };
 
 template <class T>
@@ -239,14 +239,43 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     HIPCHECK(hipHostMalloc((void **)&h->h_sum, sizeof(double) * h->SB));
     HIPCHECK(hipHostMalloc((void **)&h->h_msg, 4 * P.MSZ));
     HIPCHECK(hipHostMalloc((void **)&h->h_tmp, sizeof(double) * std::max(h->QB, h->SB)));
+    {   // lottery CDF segment tables for every K that can occur (K <= maxrank*n): pure function of K, see ttx_cdf.h
+        const int kmax = h->RM * NM;
+        if (kmax <= 16384) {
+            std::vector<ttx_cdfseg> tab((size_t)(kmax + 1) * TTX_TABSEG);
+            std::vector<int> ns(kmax + 1, 0);
+            std::vector<ttx_cdfseg> tmp(TTX_MAXSEG);
+            bool ok = true;
+            for (int K = 1; K <= kmax && ok; K++) {
+                int n_ = ttx_cdf_build(K, tmp.data());
+                if (n_ > TTX_TABSEG) { ok = false; break; }
+                ns[K] = n_;
+                memcpy(&tab[(size_t)K * TTX_TABSEG], tmp.data(), sizeof(ttx_cdfseg) * n_);
+            }
+            if (ok) {
+                ttx_cdfseg *dt; int *dn_;
+                rc = dev_alloc(h, &dt, tab.size()); if (rc) { ttx_destroy(h); return rc; }
+                rc = dev_alloc(h, &dn_, ns.size()); if (rc) { ttx_destroy(h); return rc; }
+                HIPCHECK(hipMemcpy(dt, tab.data(), sizeof(ttx_cdfseg) * tab.size(), hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(dn_, ns.data(), sizeof(int) * ns.size(), hipMemcpyHostToDevice));
+                P.cdf_tab = dt; P.cdf_ns = dn_; P.cdf_kmax = kmax;
+            }
+        }
+    }
     h->lds_par = sizeof(double) * (cfg->npar + 2);
-    h->lds_half = sizeof(double) * (cfg->npar + RM + 2) + sizeof(int) * (d + 4) + sizeof(short) * ((size_t)d * RM + 8);
+    {   // half-step LDS: index rows always fit the limit checked below; value rows (Ising C fast path) if <= 96 KB
+        const size_t VS = ((d + 7) & ~7) + 8;
+        const size_t base = sizeof(double) * (cfg->npar + RM + 4);
+        const size_t idx_bytes = sizeof(short) * ((RM + 1) * VS + 16), val_bytes = sizeof(double) * ((RM + 1) * 2 * VS + 4);
+        h->half_vals = (cfg->fun_id == TTX_FUN_ISING && P.ising_id == 1 && base + val_bytes <= 100 * 1024) ? 1 : 0;
+        h->lds_half = base + (h->half_vals ? val_bytes : idx_bytes);
+    }
     {
         const int nlotmax = 2 * h->RM + 2 * NM;
-        h->lot_batch = std::max(1, std::min(std::min(nlotmax, 512), (int)(40960 / (2 * (size_t)d))));
-        h->lds_lot = sizeof(double) * (cfg->npar + 2) + sizeof(int) * 4 * (nlotmax + 2) + sizeof(short) * ((size_t)h->lot_batch * d + 8);
+        const size_t VS = ((d + 7) & ~7) + 8;
+        h->lds_lot = sizeof(double) * (cfg->npar + 4) + sizeof(int) * 4 * (nlotmax + 4) + sizeof(short) * (2 * RM * VS + 16);
     }
-    if (h->lds_half > 160 * 1024 || h->lds_lot > 64 * 1024) { ttx_destroy(h); return fail(TTX_EINVAL, "problem too large for LDS staging (d*maxrank)"); }
+    if (h->lds_half > 160 * 1024 || h->lds_lot > 120 * 1024) { ttx_destroy(h); return fail(TTX_EINVAL, "problem too large for LDS staging (d*maxrank)"); }
     *out = h;
     return TTX_OK;
 }
@@ -477,6 +506,9 @@ static int run_impl(ttx_engine *h)
     h->recs.clear(); h->tapes.clear();
     int rc;
 
+    // kernels that may stage more than the default 64 KB of dynamic LDS (160 KB per CU on gfx950)
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_halfstep<FUN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_half));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lottery<FUN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_lot));
     // ---- reset state (lib/dmrgg.f90:96-100, 141-148, 279-288) ----
     {
         std::vector<GroupState> gs(G);
@@ -526,11 +558,11 @@ static int run_impl(ttx_engine *h)
         it++;
         const int dir = 2 - it % 2;
         for (int pp = 1; pp <= h->nbmax; pp++) {
-            { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_batch); }
+            { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp); }
             {
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
                 for (int hh = 0; hh < h->H; hh++)
-                    hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode);
+                    hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode, h->half_vals);
             }
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }
@@ -584,6 +616,17 @@ static int run_impl(ttx_engine *h)
     }
     if ((rc = readback(h))) return rc;
     HIPCHECK(hipGetLastError());
+#ifdef TTX_STAMPS
+    {   // debug build: average wall_clock64 ticks (10 ns) per phase of the lottery (0) and half-step (1) kernels
+        GroupState g0s;
+        HIPCHECK(hipMemcpy(&g0s, P.gs, sizeof(GroupState), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 2; k++) {
+            fprintf(stderr, "stamps kernel %d (n=%lld):", k, g0s.nstamp[k]);
+            for (int x = 0; x < 10; x++) fprintf(stderr, " %.2fus", g0s.nstamp[k] ? 0.01 * (double)g0s.stamp[k][x] / (double)g0s.nstamp[k] : 0.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     h->neval = (int64_t)h->h_sum[SUM_NEVAL];
     h->k_bytes[TTX_K_HALFSTEP] += h->h_sum[SUM_BYTES];
     h->rfinal = global_ranks(h);

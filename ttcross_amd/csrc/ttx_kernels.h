@@ -8,6 +8,15 @@
 #include "ttx_cdf.h"
 #include "ttx_dev.h"
 
+#ifdef TTX_STAMPS
+#define STAMP_DECL const bool t_me = (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0); long long t_prev = wall_clock64(); int t_slot = 0
+#define STAMP(gs, k) do { __syncthreads(); if (t_me) { long long t_now = wall_clock64(); (gs).stamp[k][t_slot++] += t_now - t_prev; t_prev = t_now; } } while (0)
+#define STAMP_END(gs, k) do { if (t_me) (gs).nstamp[k]++; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(gs, k)
+#define STAMP_END(gs, k)
+#endif
 #define FUN_ISING 1
 #define FUN_STDNORM 2
 #define FUN_MVN 3
@@ -93,47 +102,171 @@ __device__ __forceinline__ double eval_fun(const DevProb &P, const double *par, 
     return f_mvn(P.d, par, P.aux, P.mvn_norm, idx);
 }
 
-// Index source of one superblock entry, split into three branch-free ranges of the flattened tables staged
-// in LDS: dims 1..A from pa (stride sa), dim A+1 = self, dims A+2..m from pb (stride sb).  This replaces the
-// reference's nested vip walk (dmrgg_fun, lib/dmrgg.f90:1062-1075): every load below is independent of the
-// arithmetic chains, so the compiler can keep them in flight ahead of the dependent fp64 products.
+// Index source of one superblock entry: dims 1..A from pa[0..A-1], dim A+1 = self, dims A+2..m from pb[0..].
+// The flattened tables are staged in LDS with one CONTIGUOUS row per thread; this replaces the reference's
+// nested vip walk (dmrgg_fun, lib/dmrgg.f90:1062-1075).
 struct Src3 {
-    const short *pa; int sa, A, self; const short *pb; int sb;
+    const short *pa; int A, self; const short *pb;
     __device__ __forceinline__ int operator()(int s) const
-    { return (s <= A) ? (int)pa[(s - 1) * sa] : (s == A + 1) ? self : (int)pb[(s - A - 2) * sb]; }
+    { return (s <= A) ? (int)pa[s - 1] : (s == A + 1) ? self : (int)pb[s - A - 2]; }
+};
+// the same with two explicit dims (A+1 = s1, A+2 = s2): a lottery candidate (i,j,k,q) read straight from the
+// transposed pivot tables, pa = row of left pivot i, pb = row of right pivot q
+struct Src4 {
+    const short *pa; int A, s1, s2; const short *pb;
+    __device__ __forceinline__ int operator()(int s) const
+    { return (s <= A) ? (int)pa[s - 1] : (s == A + 1) ? s1 : (s == A + 2) ? s2 : (int)pb[s - A - 3]; }
 };
 
-// Ising C (id 1) over a Src3: identical arithmetic to f_ising (the v- and w-recurrences of
-// test_crs_ising.f90:199-204 are independent, so running them as separate loops changes nothing)
+// 8 indices with one 128-bit LDS read (rows are 16-byte aligned and padded with the valid index 1)
+struct __align__(16) Short8 { short v[8]; };
+__device__ __forceinline__ Short8 ld8(const short *p) { return *reinterpret_cast<const Short8 *>(__builtin_assume_aligned(p, 16)); }
+
+// One dependent recurrence over n table entries addressed by a 16-byte-aligned, padded index row: per chunk of
+// 8 dims one 128-bit index read and 8 independent table reads precede the 8 dependent fp64 steps; only the
+// chunk that holds the row's end is predicated.
+template <bool DESC, class STEP>
+__device__ __forceinline__ void chain8(const short *p, int n, const double *tab, STEP step)
+{
+    if (n <= 0) return;
+    const int nfull = n >> 3, rem = n & 7;
+    if (DESC && rem) {
+        Short8 ix = ld8(p + 8 * nfull); double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = tab[ix.v[k]];
+#pragma unroll
+        for (int k = 7; k >= 0; k--) if (k < rem) step(x[k]);
+    }
+#pragma unroll 2
+    for (int ch = 0; ch < nfull; ch++) {
+        const int c = 8 * (DESC ? nfull - 1 - ch : ch);
+        Short8 ix = ld8(p + c); double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = tab[ix.v[k]];
+#pragma unroll
+        for (int k = 0; k < 8; k++) step(x[DESC ? 7 - k : k]);
+    }
+    if (!DESC && rem) {
+        Short8 ix = ld8(p + 8 * nfull); double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = tab[ix.v[k]];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < rem) step(x[k]);
+    }
+}
+
+// Ising C (id 1) over aligned rows.  Same arithmetic as f_ising: the v- and w-recurrences of
+// test_crs_ising.f90:199-204 are independent, so they run as separate loops.
 __device__ __forceinline__ double f_ising_c3(int m, int n1, const double *par, const Src3 &S)
 {
     const double *nodes = par - 1, *weights = par + n1 - 1;
     const int A = S.A, nb = m - A - 1;
     double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
-#pragma unroll 4
-    for (int x = nb - 1; x >= 0; x--) { vk = vk * nodes[S.pb[x * S.sb]]; v = v + vk; }
-    vk = vk * nodes[S.self]; v = v + vk;
-#pragma unroll 4
-    for (int x = A - 1; x >= 0; x--) { vk = vk * nodes[S.pa[x * S.sa]]; v = v + vk; }
-#pragma unroll 4
-    for (int x = 0; x < A; x++) { wk = wk * nodes[S.pa[x * S.sa]]; w = w + wk; }
-    wk = wk * nodes[S.self]; w = w + wk;
-#pragma unroll 4
-    for (int x = 0; x < nb; x++) { wk = wk * nodes[S.pb[x * S.sb]]; w = w + wk; }
+    auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
+    auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
+    chain8<true>(S.pb, nb, nodes, vstep);
+    vstep(nodes[S.self]);
+    chain8<true>(S.pa, A, nodes, vstep);
+    chain8<false>(S.pa, A, nodes, wstep);
+    wstep(nodes[S.self]);
+    chain8<false>(S.pb, nb, nodes, wstep);
     double b = 1.0 / (v * w);
     double f = 2 * b;
-#pragma unroll 4
-    for (int x = 0; x < A; x++) f = f * weights[S.pa[x * S.sa]];
-    f = f * weights[S.self];
-#pragma unroll 4
-    for (int x = 0; x < nb; x++) f = f * weights[S.pb[x * S.sb]];
+    auto fstep = [&](double xv) { f = f * xv; };
+    chain8<false>(S.pa, A, weights, fstep);
+    fstep(weights[S.self]);
+    chain8<false>(S.pb, nb, weights, fstep);
+    return f;
+}
+__device__ __forceinline__ double f_ising_c4(int m, int n1, const double *par, const Src4 &S)
+{
+    const double *nodes = par - 1, *weights = par + n1 - 1;
+    const int A = S.A, nb = m - A - 2;
+    double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
+    auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
+    auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
+    chain8<true>(S.pb, nb, nodes, vstep);
+    vstep(nodes[S.s2]); vstep(nodes[S.s1]);
+    chain8<true>(S.pa, A, nodes, vstep);
+    chain8<false>(S.pa, A, nodes, wstep);
+    wstep(nodes[S.s1]); wstep(nodes[S.s2]);
+    chain8<false>(S.pb, nb, nodes, wstep);
+    double b = 1.0 / (v * w);
+    double f = 2 * b;
+    auto fstep = [&](double xv) { f = f * xv; };
+    chain8<false>(S.pa, A, weights, fstep);
+    fstep(weights[S.s1]); fstep(weights[S.s2]);
+    chain8<false>(S.pb, nb, weights, fstep);
+    return f;
+}
+template <int FUN>
+__device__ __forceinline__ double eval_src4(const DevProb &P, const double *par, const Src4 &S)
+{
+    if (FUN == FUN_ISING && P.ising_id == 1) return f_ising_c4(P.d, P.n[1], par, S);
+    return eval_fun<FUN>(P, par, S);
+}
+
+// Same recurrences over rows of VALUES (node / weight doubles staged in LDS, 16-byte aligned, padded): a step
+// is one LDS read (two doubles per ds_read_b128) + the dependent multiply(+add).  A lone wave issues one VALU
+// instruction per 4 cycles, so the instruction count per step -- not the fp64 latency -- bounds these chains.
+struct __align__(16) Double2 { double a, b; };
+template <bool DESC, class STEP>
+__device__ __forceinline__ void chain8v(const double *p, int n, STEP step)
+{
+    if (n <= 0) return;
+    const int nfull = n >> 3, rem = n & 7;
+    if (DESC && rem) {
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Double2 t = *reinterpret_cast<const Double2 *>(p + 8 * nfull + 2 * k); x[2 * k] = t.a; x[2 * k + 1] = t.b; }
+#pragma unroll
+        for (int k = 7; k >= 0; k--) if (k < rem) step(x[k]);
+    }
+#pragma unroll 2
+    for (int ch = 0; ch < nfull; ch++) {
+        const int c = 8 * (DESC ? nfull - 1 - ch : ch);
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Double2 t = *reinterpret_cast<const Double2 *>(p + c + 2 * k); x[2 * k] = t.a; x[2 * k + 1] = t.b; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) step(x[DESC ? 7 - k : k]);
+    }
+    if (!DESC && rem) {
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Double2 t = *reinterpret_cast<const Double2 *>(p + 8 * nfull + 2 * k); x[2 * k] = t.a; x[2 * k + 1] = t.b; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < rem) step(x[k]);
+    }
+}
+// dims 1..A: (an, aw); dim A+1: (sn, sw); dims A+2..m: (bn, bw)   [n = node values, w = weight values]
+__device__ __forceinline__ double f_ising_c3v(int m, int A, const double *an, const double *aw, double sn, double sw,
+                                              const double *bn, const double *bw)
+{
+    const int nb = m - A - 1;
+    double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
+    auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
+    auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
+    chain8v<true>(bn, nb, vstep);
+    vstep(sn);
+    chain8v<true>(an, A, vstep);
+    chain8v<false>(an, A, wstep);
+    wstep(sn);
+    chain8v<false>(bn, nb, wstep);
+    double b = 1.0 / (v * w);
+    double f = 2 * b;
+    auto fstep = [&](double xv) { f = f * xv; };
+    chain8v<false>(aw, A, fstep);
+    fstep(sw);
+    chain8v<false>(bw, nb, fstep);
     return f;
 }
 
-template <int FUN>
+// aligned = rows are 16-byte aligned and padded (half-step / lottery staging); else the generic accessor
+template <int FUN, bool ALIGNED>
 __device__ __forceinline__ double eval_src3(const DevProb &P, const double *par, const Src3 &S)
 {
-    if (FUN == FUN_ISING && P.ising_id == 1) return f_ising_c3(P.d, P.n[1], par, S);
+    if (ALIGNED && FUN == FUN_ISING && P.ising_id == 1) return f_ising_c3(P.d, P.n[1], par, S);
     return eval_fun<FUN>(P, par, S);
 }
 
@@ -220,7 +353,7 @@ struct FixIdx { const int *ind; int self, selfval; __device__ __forceinline__ in
 template <int FUN>
 __global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int nn, int shift_lo, int shift_hi)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     double *par = dyn;
     __shared__ double sha[4], shv[4]; __shared__ int shi[4];
     const int g = blockIdx.x, tid = threadIdx.x;
@@ -254,7 +387,7 @@ __global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int n
 template <int FUN>
 __global__ __launch_bounds__(256) void k_init_fibers(DevProb P)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     double *par = dyn;
     __shared__ double shm[4];
     const int g = blockIdx.y, tid = threadIdx.x;
@@ -342,9 +475,9 @@ __global__ void k_init_final(DevProb P)
 // one block per group
 // ------------------------------------------------------------------------------------------------
 template <int FUN>
-__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int LB)
+__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     __shared__ StepState st;
     __shared__ int zc[128], zr[128], zcs[128], zrs[128], keepc[128], keepr[128];
     __shared__ int nzc, nzr, nsc, nsr;
@@ -352,6 +485,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     __shared__ double sha[8], shv[8]; __shared__ int shi[8];
     const int g = blockIdx.x, tid = threadIdx.x, m = P.d;
     GroupState &gs = P.gs[g];
+    STAMP_DECL;
     int *r = P.r + (size_t)g * (m + 2);
     if (tid == 0) {
         if (pp == 1) {                                        // sweep start, :325-327
@@ -370,13 +504,28 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     }
     __syncthreads();
     if (!st.active) { if (tid == 0) gs.S[0] = st; return; }
+    STAMP(gs, 0);   // 0: state
     const int p = st.p, r0 = st.r0, r1 = st.r1, r2 = st.r2, n1 = st.n1, n2 = st.n2, first = gs.first;
     const int nlot = r0 + n1 + n2 + r2;
-    // LDS: par | lot[4*nlot] (int) | rows[LB*m] (short)
+    // LDS: par | lot[4*nlot] (int) | LT[r0][VS] | RT[r2][VS] (short): the pivot tables of bonds p-1 and p+1,
+    // transposed so that the multi-index of a left / right pivot is one contiguous 16-byte-aligned row
+    const int VS = ((m + 7) & ~7) + 8;
     double *par = dyn;
-    int *lot = (int *)(dyn + P.npar);
-    short *rows = (short *)(lot + 4 * nlot);
+    int *lot = (int *)(dyn + ((P.npar + 1) & ~1));
+    short *LT = (short *)(lot + ((4 * nlot + 3) & ~3));
+    short *RT = LT + (size_t)r0 * VS;
+    const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
     for (int x = tid; x < P.npar; x += blockDim.x) par[x] = P.par[x];
+    for (int x = tid; x < r0 * VS; x += blockDim.x) { const int c = x / VS, o = x - c * VS; LT[x] = (o < p - 1) ? Lt[(size_t)o * P.RM + c] : (short)1; }
+    for (int x = tid; x < r2 * VS; x += blockDim.x) { const int c = x / VS, o = x - c * VS; RT[x] = (o < m - p - 1) ? Rt[(size_t)o * P.RM + c] : (short)1; }
+    // rnd.f90:120: d(nlot,2) column-major from the (never seeded) run-time generator.  Draw #k comes from the
+    // generator word 48271^(2k+1): split as [48271^(2 pos+1)] * [48271^2]^il so that the long jump-ahead is done
+    // once per block (threads 32/33) while every thread raises the short power
+    __shared__ unsigned long long sA[2];
+    if (tid == 32) sA[0] = ttx_minstd_pow(2 * gs.rngpos + 1);
+    if (tid == 33) sA[1] = ttx_minstd_pow(2 * (gs.rngpos + nlot) + 1);
+    unsigned long long bil = ttx_minstd_pow(2ull * tid);
     // zero-weight positions (existing pivots), :432-439
     const int *vp = vip_ptr(P, g, p, first);
     if (tid < r1) {
@@ -403,50 +552,40 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         if (tid == r1 - 1) { nzc = pc + keepc[tid]; nzr = pr + keepr[tid]; }
     }
     __syncthreads();
+    STAMP(gs, 0);   // 1: tables + powers + zero lists
     const int Kc = r0 * n1 - nzc, Kr = n2 * r2 - nzr;
-    if (tid == 0) nsc = ttx_cdf_build(Kc, segc);
-    if (tid == 64) nsr = ttx_cdf_build(Kr, segr);
-    __syncthreads();
-    // rnd.f90:120-124: d(nlot,2) column-major from the (never seeded) run-time generator; :447-452 decode
-    for (int il = tid; il < nlot; il += blockDim.x) {
-        double d1 = ttx_flang_draw(gs.rngpos + il), d2 = ttx_flang_draw(gs.rngpos + nlot + il);
-        int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);
-        int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
-        lot[4 * il] = (x - 1) % r0 + 1; lot[4 * il + 1] = (x - 1) / r0 + 1;
-        lot[4 * il + 2] = (y - 1) % n2 + 1; lot[4 * il + 3] = (y - 1) / n2 + 1;
+    if (P.cdf_tab && Kc <= P.cdf_kmax && Kr <= P.cdf_kmax) {
+        // segment tables depend on K only: precomputed at ttx_create, copied here
+        if (tid < 64) { if (tid < P.cdf_ns[Kc]) segc[tid] = P.cdf_tab[(size_t)Kc * TTX_TABSEG + tid]; if (tid == 0) nsc = P.cdf_ns[Kc]; }
+        else if (tid < 128) { const int t2 = tid - 64; if (t2 < P.cdf_ns[Kr]) segr[t2] = P.cdf_tab[(size_t)Kr * TTX_TABSEG + t2]; if (t2 == 0) nsr = P.cdf_ns[Kr]; }
+    } else {
+        if (tid == 0) nsc = ttx_cdf_build(Kc, segc);
+        if (tid == 64) nsr = ttx_cdf_build(Kr, segr);
     }
     __syncthreads();
-    const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
-    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    STAMP(gs, 0);   // 2: cdf
     double ma = 0.0;
     double ba = -1.0, bv = 0.0; int bi = INT_MAX;
-    for (int b0 = 0; b0 < nlot; b0 += LB) {
-        const int nbat = min(LB, nlot - b0);
-        // stage the full multi-index of every candidate of the batch: independent, pipelined loads
-        for (int x = tid; x < nbat * m; x += blockDim.x) {
-            int il = b0 + x / m, s = x % m + 1;
-            int i = lot[4 * il] - 1, q = lot[4 * il + 3] - 1;
-            rows[x] = (s < p) ? Lt[(size_t)(s - 1) * P.RM + i] : (s == p) ? (short)lot[4 * il + 1]
-                    : (s == p + 1) ? (short)lot[4 * il + 2] : Rt[(size_t)(s - p - 2) * P.RM + q];
-        }
-        __syncthreads();
-        if (tid < nbat) {
-            const int il = b0 + tid;
-            const short *row = rows + (size_t)tid * m;
-            Src3 sx{row, 1, p - 1, (int)row[p - 1], row + p, 1};
-            double f = eval_src3<FUN>(P, par, sx);                   // :455-463
-            ma = fmax(ma, fabs(f));
-            int i = lot[4 * il], j = lot[4 * il + 1], k = lot[4 * il + 2], q = lot[4 * il + 3];
-            const double *c = Cp + (i - 1) + (size_t)P.RM * (j - 1), *w = Wq + (k - 1) + (size_t)P.NM * (q - 1);
-            double t = 0.0;                                          // ddot, :474
+    for (int il = tid; il < nlot; il += blockDim.x) {
+        double d1, d2;
+        if (il < (int)blockDim.x) { d1 = ttx_flang_from_word(ttx_mulmod31(sA[0], bil)); d2 = ttx_flang_from_word(ttx_mulmod31(sA[1], bil)); }
+        else { d1 = ttx_flang_draw(gs.rngpos + il); d2 = ttx_flang_draw(gs.rngpos + nlot + il); }
+        const int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);      // rnd.f90:122-123
+        const int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
+        const int i = (x - 1) % r0 + 1, j = (x - 1) / r0 + 1, k = (y - 1) % n2 + 1, q = (y - 1) / n2 + 1;   // :447-452
+        lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
+        Src4 sx{LT + (size_t)(i - 1) * VS, p - 1, j, k, RT + (size_t)(q - 1) * VS};
+        const double f = eval_src4<FUN>(P, par, sx);                               // :455-463
+        ma = fmax(ma, fabs(f));
+        const double *c = Cp + (i - 1) + (size_t)P.RM * (j - 1), *w = Wq + (k - 1) + (size_t)P.NM * (q - 1);
+        double t = 0.0;                                                            // ddot, :474
 #pragma unroll 8
-            for (int s = 0; s < r1; s++) t = t + c[P.SS * s] * w[P.SW * s];
-            double b = f - t;
-            double a = fabs(b);
-            if (a > ba || (a == ba && il < bi)) { ba = a; bv = b; bi = il; }
-        }
-        __syncthreads();
+        for (int s = 0; s < r1; s++) t = t + c[P.SS * s] * w[P.SW * s];
+        const double b = f - t;
+        const double a = fabs(b);
+        if (a > ba || (a == ba && il < bi)) { ba = a; bv = b; bi = il; }
     }
+    STAMP(gs, 0);   // 3: selection + eval + ddot
     ma = block_max(ma, sha);
     block_argmax(ba, bv, bi, sha, shv, shi);
     if (tid == 0) {
@@ -457,6 +596,8 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         st.pivot = bv;
         gs.S[0] = st;
     }
+    STAMP(gs, 0);   // 7: reductions + state
+    STAMP_END(gs, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -467,51 +608,85 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
 // no residual).
 // ------------------------------------------------------------------------------------------------
 template <int FUN>
-__global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir, int mode)
+__global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir, int mode, int vals)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     __shared__ StepState cur;
     __shared__ double sha[4], shv[4]; __shared__ int shi[4];
     const int g = blockIdx.y, tid = threadIdx.x, m = P.d;
     GroupState &gs = P.gs[g];
+    STAMP_DECL;
     if (tid == 0) { cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]); }
     __syncthreads();
     if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
+    STAMP(gs, 1);   // 0: resolve
     const bool iscol = (mode == 1) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
     const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
     const int nf = iscol ? r0 * n1 : n2 * r2;
     if (blockIdx.x * TTX_BLK >= nf) return;
-    // LDS: par | xs[RM] | fxs[d+2] (short) | vt[d*RM] (short)
-    double *par = dyn, *xs = dyn + P.npar;
-    short *fxs = (short *)(xs + P.RM);
-    short *vt = fxs + ((m + 2 + 3) & ~3);
+    // LDS: par | xs[RM] | then either VALUE rows (Ising C when they fit: node and weight doubles, one 16-byte
+    // aligned row per varying index + one fixed row) or INDEX rows (short) for the generic integrands
+    const int VS = ((m + 7) & ~7) + 8;
+    double *par = dyn, *xs = dyn + ((P.npar + 1) & ~1);
+    double *vbase = xs + ((P.RM + 1) & ~1);
     const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
     const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
     for (int x = tid; x < P.npar; x += TTX_BLK) par[x] = P.par[x];
-    int vrows, vcols;
-    if (iscol) {   // varying: left pivot i (dims 1..p-1) and j; fixed: kk and the right multi-index of qq (dims p+1..m)
-        vrows = p - 1; vcols = r0;
-        for (int x = tid; x < vrows * vcols; x += TTX_BLK) vt[x] = Lt[(size_t)(x / vcols) * P.RM + (x % vcols)];
-        for (int x = tid; x < m - p; x += TTX_BLK) fxs[x] = (x == 0) ? (short)cur.kk : Rt[(size_t)(x - 1) * P.RM + (cur.qq - 1)];
-        for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Wq[(cur.kk - 1) + (size_t)P.NM * (cur.qq - 1) + P.SW * s];
-    } else {       // varying: k and right pivot q (dims p+2..m); fixed: left multi-index of ii and jj (dims 1..p)
-        vrows = m - p - 1; vcols = r2;
-        for (int x = tid; x < vrows * vcols; x += TTX_BLK) vt[x] = Rt[(size_t)(x / vcols) * P.RM + (x % vcols)];
-        for (int x = tid; x < p; x += TTX_BLK) fxs[x] = (x == p - 1) ? (short)cur.jj : Lt[(size_t)x * P.RM + (cur.ii - 1)];
-        for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Cp[(cur.ii - 1) + (size_t)P.RM * (cur.jj - 1) + P.SS * s];
+    const int vrows = iscol ? p - 1 : m - p - 1, vcols = iscol ? r0 : r2;
+    const bool usev = (FUN == FUN_ISING) && (P.ising_id == 1) && (vals != 0);
+    const int n1m = P.n[1];
+    __syncthreads();      // par is read below when staging values
+    if (usev) {
+        // rows: [0 .. vcols) varying index, row vcols = fixed side; each row: VS node values then VS weight values
+        double *fn = vbase + (size_t)vcols * 2 * VS, *fw = fn + VS;
+        for (int x = tid; x < vcols * VS; x += TTX_BLK) {
+            const int c = x / VS, o = x % VS;
+            int ix = 1;
+            if (o < vrows) ix = iscol ? Lt[(size_t)o * P.RM + c] : Rt[(size_t)o * P.RM + c];
+            vbase[(size_t)c * 2 * VS + o] = par[ix - 1];
+            vbase[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
+        }
+        for (int x = tid; x < VS; x += TTX_BLK) {
+            int ix = 1;
+            if (iscol) { if (x == 0) ix = cur.kk; else if (x < m - p) ix = Rt[(size_t)(x - 1) * P.RM + (cur.qq - 1)]; }
+            else       { if (x < p - 1) ix = Lt[(size_t)x * P.RM + (cur.ii - 1)]; else if (x == p - 1) ix = cur.jj; }
+            fn[x] = par[ix - 1]; fw[x] = par[n1m + ix - 1];
+        }
     }
+    short *fxs = (short *)vbase;
+    short *vt = fxs + VS;
+    if (!usev) {
+        if (iscol) {   // varying: left pivot i (dims 1..p-1) and j; fixed: kk and the right multi-index of qq (dims p+1..m)
+            for (int x = tid; x < vcols * VS; x += TTX_BLK) { const int c = x / VS, o = x % VS; vt[x] = (o < vrows) ? Lt[(size_t)o * P.RM + c] : (short)1; }
+            for (int x = tid; x < VS; x += TTX_BLK) fxs[x] = (x == 0) ? (short)cur.kk : (x < m - p) ? Rt[(size_t)(x - 1) * P.RM + (cur.qq - 1)] : (short)1;
+        } else {       // varying: k and right pivot q (dims p+2..m); fixed: left multi-index of ii and jj (dims 1..p)
+            for (int x = tid; x < vcols * VS; x += TTX_BLK) { const int c = x / VS, o = x % VS; vt[x] = (o < vrows) ? Rt[(size_t)o * P.RM + c] : (short)1; }
+            for (int x = tid; x < VS; x += TTX_BLK) fxs[x] = (x < p - 1) ? Lt[(size_t)x * P.RM + (cur.ii - 1)] : (x == p - 1) ? (short)cur.jj : (short)1;
+        }
+    }
+    if (iscol) for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Wq[(cur.kk - 1) + (size_t)P.NM * (cur.qq - 1) + P.SW * s];
+    else       for (int s = tid; s < r1; s += TTX_BLK) xs[s] = Cp[(cur.ii - 1) + (size_t)P.RM * (cur.jj - 1) + P.SS * s];
     __syncthreads();
+    STAMP(gs, 1);   // 1: staging
     const int t = blockIdx.x * TTX_BLK + tid;
     const bool live = t < nf;
     double a = 0.0;
     int u = 0, v = 0;                         // col: (i,j) 0-based ; row: (k,q) 0-based
     if (live) {
-        Src3 sx;
-        if (iscol) { u = t % r0; v = t / r0; sx.pa = vt + u; sx.sa = vcols; sx.A = p - 1; sx.self = v + 1; sx.pb = fxs; sx.sb = 1; }
-        else       { u = t % n2; v = t / n2; sx.pa = fxs; sx.sa = 1; sx.A = p; sx.self = u + 1; sx.pb = vt + v; sx.sb = vcols; }
-        a = eval_src3<FUN>(P, par, sx);                                       // :520-526 / :553-559
+        if (iscol) { u = t % r0; v = t / r0; } else { u = t % n2; v = t / n2; }
+        if (usev) {
+            const double *fn = vbase + (size_t)vcols * 2 * VS, *fw = fn + VS;
+            if (iscol) { const double *rn = vbase + (size_t)u * 2 * VS; a = f_ising_c3v(m, p - 1, rn, rn + VS, par[v], par[n1m + v], fn, fw); }
+            else       { const double *rn = vbase + (size_t)v * 2 * VS; a = f_ising_c3v(m, p, fn, fw, par[u], par[n1m + u], rn, rn + VS); }
+        } else {
+            Src3 sx;
+            if (iscol) { sx.pa = vt + (size_t)u * VS; sx.A = p - 1; sx.self = v + 1; sx.pb = fxs; }
+            else       { sx.pa = fxs; sx.A = p; sx.self = u + 1; sx.pb = vt + (size_t)v * VS; }
+            a = eval_src3<FUN, true>(P, par, sx);                             // :520-526 / :553-559
+        }
         (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
     }
+    STAMP(gs, 1);   // 2: eval
     double mx = block_max(live ? fabs(a) : 0.0, sha);
     if (tid == 0) atomic_max_pos(&gs.amax, mx);                               // :531 / :564
     const int crs = cur.crs + 1;
@@ -534,6 +709,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             }
             ab = fabs(b); bi = t;
         }
+        STAMP(gs, 1);   // 3: residual
         block_argmax(ab, b, bi, sha, shv, shi);
         if (tid == 0) { Partial pr; pr.absmax = ab; pr.val = b; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][blockIdx.x] = pr; }
     }
@@ -547,6 +723,8 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
         gs.bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
         gs.n_resid += resid ? 1 : 0;
     }
+    STAMP(gs, 1);   // 4: argmax + state
+    STAMP_END(gs, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -557,7 +735,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TTX_BLK) void k_accept(DevProb P, int H, int nA)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     __shared__ StepState cur;
     __shared__ int s_upd;
     __shared__ double s_bc;
@@ -800,7 +978,7 @@ struct ListIdx { const int *ind; __device__ __forceinline__ int operator()(int s
 template <int FUN>
 __global__ void k_eval_list(DevProb P, long long npts, const int *ind, double *out)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     for (int x = threadIdx.x; x < P.npar; x += blockDim.x) dyn[x] = P.par[x];
     __syncthreads();
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -945,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_exch_apply(DevProb P)
 template <int FUN>
 __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     __shared__ double s_bc;
     const int g = blockIdx.y, tid = threadIdx.x, m = P.d;
     GroupState &gs = P.gs[g];
@@ -969,8 +1147,8 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
                 row[s - 1] = (s < p) ? Lt[(size_t)(s - 1) * P.RM + (vp[0] - 1)] : (s == p) ? (short)vp[1] : (s == p + 1) ? (short)(k + 1) : Rt[(size_t)(s - p - 2) * P.RM + snew];
             __syncthreads();
             if (tid == rrp) {
-                Src3 sx{row, 1, p - 1, (int)row[p - 1], row + p, 1};
-                a = eval_src3<FUN>(P, par, sx);
+                Src3 sx{row, p - 1, (int)row[p - 1], row + p};
+                a = eval_src3<FUN, false>(P, par, sx);
                 atomic_max_pos(&gs.amax, fabs(a));
                 if (k == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n2);   // :936
             }
@@ -1002,8 +1180,8 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
                 row[s - 1] = (s < p) ? Lt[(size_t)(s - 1) * P.RM + inew] : (s == p) ? (short)(j + 1) : (s == p + 1) ? (short)vp[2] : Rt[(size_t)(s - p - 2) * P.RM + (vp[3] - 1)];
             __syncthreads();
             if (tid == rrp) {
-                Src3 sx{row, 1, p - 1, (int)row[p - 1], row + p, 1};
-                y = eval_src3<FUN>(P, par, sx);
+                Src3 sx{row, p - 1, (int)row[p - 1], row + p};
+                y = eval_src3<FUN, false>(P, par, sx);
                 atomic_max_pos(&gs.amax, fabs(y));
                 if (j == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n1);
             }
