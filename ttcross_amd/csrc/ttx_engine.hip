@@ -533,7 +533,7 @@ static int run_impl(ttx_engine *h)
         hipLaunchKernelGGL(k_init_samples<FUN>, dim3(G), dim3(256), h->lds_par, st, P, snum, nn, 0, 0);
         hipLaunchKernelGGL(k_init_fibers<FUN>, dim3(h->NC, G), dim3(256), h->lds_par, st, P);
         hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(k_init_final, dim3(G), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_init_final, dim3(G), dim3(256), 0, st, P);
     }
     if ((rc = readback(h))) return rc;
     HIPCHECK(hipGetLastError());
@@ -567,16 +567,16 @@ static int run_impl(ttx_engine *h)
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }
         {   // per-sweep exchange between bond groups (:763-961)
-            KScope ks(h, TTX_K_EXCHANGE, nproc > 1 ? 5 : 3);
+            KScope ks(h, TTX_K_EXCHANGE, (h->W > 1 ? 4 : 2) + (nproc > 1 ? 1 : 0));
             hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
-            hipLaunchKernelGGL(k_exch_localmax, dim3(1), dim3(64), 0, st, P);
-            if ((rc = xfer_neighbours(h))) return rc;
-            if ((rc = allreduce_dev(h, P.redsend, P.redrecv, 4, 1))) return rc;
-            hipLaunchKernelGGL(k_exch_max, dim3(1), dim3(64), 0, st, P);
-            if (nproc > 1) {
-                hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
-                hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8), st, P);
+            if (h->W > 1) {
+                hipLaunchKernelGGL(k_exch_localmax, dim3(1), dim3(64), 0, st, P);
+                if ((rc = xfer_neighbours(h))) return rc;
+                if ((rc = allreduce_dev(h, P.redsend, P.redrecv, 4, 1))) return rc;
             }
+            hipLaunchKernelGGL(k_exch_max_apply, dim3(G), dim3(256), 0, st, P, h->W > 1 ? 1 : 0, nproc > 1 ? 1 : 0);
+            if (nproc > 1)
+                hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8), st, P);
         }
         if (P.has_quad) {
             KScope ks(h, TTX_K_QUAD, nproc > 1 ? 3 : 2);

@@ -443,31 +443,37 @@ __global__ __launch_bounds__(256) void k_init_factors(DevProb P)
     }
 }
 
-// pivotmax_prev (:234) and the group's factor of the initial quadrature value (:250-258)
-__global__ void k_init_final(DevProb P)
+// pivotmax_prev (:234) and the group's factor of the initial quadrature value (:250-258); one block per group,
+// one thread per core for the ddot, then the ordered product
+__global__ __launch_bounds__(256) void k_init_final(DevProb P)
 {
-    const int g = blockIdx.x;
+    __shared__ double dots[256];
+    const int g = blockIdx.x, tid = threadIdx.x;
     GroupState &gs = P.gs[g];
-    if (threadIdx.x != 0) return;
-    gs.pivotmax_prev = gs.amax;
-    gs.pivotmax = -1.0; gs.pivotmin = -1.0;
+    const bool lastgroup = (gs.last + 1 == P.d && gs.gglobal == P.nprocs - 1);
+    const int ncore = gs.last - gs.first + 1 + (lastgroup ? 1 : 0);
     double val = 1.0;
     if (P.has_quad) {
-        for (int p = gs.first; p <= gs.last; p++) {
-            const double *A = core_ptr(P, P.arg, g, p, gs.first), *w = P.quadw + (size_t)p * P.NM;
-            double t = 0.0;
-            for (int j = 0; j < P.n[p]; j++) t = t + A[(size_t)P.RM * j] * w[j];
-            val = val * t / inv_ptr(P, g, p, gs.first)[0];
-        }
-        if (gs.last + 1 == P.d && gs.gglobal == P.nprocs - 1) {
-            int p = P.d;
-            const double *A = core_ptr(P, P.arg, g, p, gs.first), *w = P.quadw + (size_t)p * P.NM;
-            double t = 0.0;
-            for (int j = 0; j < P.n[p]; j++) t = t + A[(size_t)P.RM * j] * w[j];
-            val = val * t;
+        for (int c0 = 0; c0 < ncore; c0 += 256) {
+            const int c = c0 + tid;
+            if (c < ncore) {
+                const int p = gs.first + c;
+                const double *A = core_ptr(P, P.arg, g, p, gs.first), *w = P.quadw + (size_t)p * P.NM;
+                double t = 0.0;
+                for (int j = 0; j < P.n[p]; j++) t = t + A[(size_t)P.RM * j] * w[j];
+                dots[tid] = t;
+            }
+            __syncthreads();
+            if (tid == 0)
+                for (int c2 = c0; c2 < min(ncore, c0 + 256); c2++) {
+                    const int p = gs.first + c2;
+                    if (p <= gs.last) val = val * dots[c2 - c0] / inv_ptr(P, g, p, gs.first)[0];
+                    else val = val * dots[c2 - c0];
+                }
+            __syncthreads();
         }
     }
-    gs.initval = val;
+    if (tid == 0) { gs.pivotmax_prev = gs.amax; gs.pivotmax = -1.0; gs.pivotmin = -1.0; gs.initval = val; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1027,10 +1033,10 @@ __global__ void k_lottery_only(int npnt, int m, int n, int nz, const int *zcol, 
 // through every rank (which makes far bonds lag by one sweep per hop), the owner ships the FLATTENED
 // multi-index of its new boundary pivot to its direct neighbour -- the only rank that ever evaluates with it.
 // ------------------------------------------------------------------------------------------------
-// one block per group: pack both outgoing messages and the group's entry of the MAX all-reduce
-__global__ __launch_bounds__(256) void k_exch_pack(DevProb P)
+// pack both outgoing messages of group g and its entry of the MAX all-reduce (called by every thread of a block)
+__device__ __forceinline__ void exch_pack_group(const DevProb &P, int g)
 {
-    const int g = blockIdx.x, tid = threadIdx.x, m = P.d;
+    const int tid = threadIdx.x, m = P.d;
     GroupState &gs = P.gs[g];
     const int first = gs.first, last = gs.last;
     const int *r = P.r + (size_t)g * (m + 2), *rr = P.rr + (size_t)g * (m + 2), *upd = P.upd + (size_t)g * (m + 2);
@@ -1072,6 +1078,10 @@ __global__ __launch_bounds__(256) void k_exch_pack(DevProb P)
     }
 }
 
+// device functions shared by the multi-GPU kernels (one block per group) and the fused single-GPU kernel
+__device__ __forceinline__ void exch_pack_group(const DevProb &P, int g);
+__device__ __forceinline__ void exch_apply_group(const DevProb &P, int g);
+
 // MAX all-reduce (:861), stage 1: combine the groups of this GPU into redsend[0..2]
 __global__ void k_exch_localmax(DevProb P)
 {
@@ -1093,9 +1103,9 @@ __global__ void k_exch_max(DevProb P)
 }
 
 // apply the neighbours' pivots: ranks, index tables, inv of the left boundary bond (:822-850, :1209-1246)
-__global__ __launch_bounds__(256) void k_exch_apply(DevProb P)
+__device__ __forceinline__ void exch_apply_group(const DevProb &P, int g)
 {
-    const int g = blockIdx.x, tid = threadIdx.x, m = P.d;
+    const int tid = threadIdx.x, m = P.d;
     GroupState &gs = P.gs[g];
     const int first = gs.first, last = gs.last;
     int *r = P.r + (size_t)g * (m + 2), *upd = P.upd + (size_t)g * (m + 2);
@@ -1115,6 +1125,25 @@ __global__ __launch_bounds__(256) void k_exch_apply(DevProb P)
         if (u) { short *Rt = R_ptr(P, g, br, first); for (int x = tid; x < m - br; x += blockDim.x) Rt[(size_t)x * P.RM + (rnew - 1)] = (short)ix[x]; }
         if (tid == 0) { upd[br] = u; r[br] = rnew; }
     }
+}
+
+__global__ __launch_bounds__(256) void k_exch_pack(DevProb P) { exch_pack_group(P, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_exch_apply(DevProb P) { exch_apply_group(P, blockIdx.x); }
+
+// MAX all-reduce result (:867-870, :961) folded into the apply launch: every block reduces the same inputs and
+// writes only its own group.  from_recv: P.redrecv already holds the job-wide maxima (after the RCCL all-reduce)
+__global__ __launch_bounds__(256) void k_exch_max_apply(DevProb P, int from_recv, int do_apply)
+{
+    const int g = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double a = -1e300, b = -1e300, c = -1e300;
+        if (from_recv) { a = P.redrecv[0]; b = P.redrecv[1]; c = P.redrecv[2]; }
+        else for (int x = 0; x < P.G; x++) { a = fmax(a, P.red[4 * x]); b = fmax(b, P.red[4 * x + 1]); c = fmax(c, P.red[4 * x + 2]); }
+        GroupState &gs = P.gs[g];
+        gs.amax = a; gs.pivotmax = b; gs.pivotmin = (-c == 999e9) ? -1.0 : -c;
+        gs.pivotmax_prev = b;
+    }
+    if (do_apply) exch_apply_group(P, g);
 }
 
 // grow the boundary cores with the neighbours' fibers, evaluate the corner entries, LU-apply
