@@ -22,7 +22,8 @@ def _run_both(s, r, piv, nproc=1):
 
 
 ISING_CASES = [("c", 6, 33, 20, 2), ("c", 6, 33, 10, 1), ("c", 5, 17, 8, 0), ("c", 8, 25, 12, 3), ("d", 6, 33, 12, 2),
-               ("e", 5, 33, 12, 2), ("d", 12, 33, 10, 2), ("c", 16, 51, 32, 2), ("c", 64, 51, 32, 2)]
+               ("e", 5, 33, 12, 2), ("d", 12, 33, 10, 2), ("c", 16, 51, 32, 2), ("c", 64, 51, 32, 2),
+               ("c", 5, 9, 6, -1), ("d", 4, 11, 5, -1), ("d", 32, 33, 12, 2)]
 
 
 @pytest.mark.parametrize("kind,m,n,r,piv", ISING_CASES, ids=[f"{c[0]}{c[1]}_n{c[2]}_r{c[3]}_p{c[4]}" for c in ISING_CASES])
@@ -42,11 +43,11 @@ def test_ising_sweep_bit_exact(kind, m, n, r, piv):
         assert np.array_equal(tt.core(k), oo["cores"][k - 1]), f"core {k} differs"
     assert tt.quad(s["quad"]) == oo["value"]
     if s["tru"]:      # known-answer check (the driver's `correct digits`); low-rank cases stop at ~1e-7
-        assert abs(1 - tt.quad(s["quad"]) / s["tru"]) < (1e-12 if r >= 32 else 1e-6)
+        assert abs(1 - tt.quad(s["quad"]) / s["tru"]) < (1e-12 if r >= 32 else 1e-6 if n >= 17 else 1e-3)
 
 
 GROUP_CASES = [("c", 6, 33, 20, 2, 2), ("c", 6, 33, 20, 2, 4), ("d", 8, 33, 10, 2, 3), ("c", 16, 51, 32, 2, 8), ("c", 64, 51, 32, 2, 8),
-               ("c", 64, 51, 32, 2, 5), ("e", 9, 33, 12, 3, 7)]
+               ("c", 64, 51, 32, 2, 5), ("e", 9, 33, 12, 3, 7), ("c", 7, 9, 5, -1, 2), ("c", 12, 17, 6, 0, 3)]
 
 
 @pytest.mark.parametrize("kind,m,n,r,piv,nproc", GROUP_CASES, ids=[f"{c[0]}{c[1]}_r{c[3]}_p{c[4]}_np{c[5]}" for c in GROUP_CASES])

@@ -103,6 +103,8 @@ struct DevProb {
     double *qwork;                 // [(nprocs+2)*RM*RM] scratch of the quadrature tree
     double *sumsend, *sumrecv;     // per-sweep job summary (SUM all-reduce): see SUM_* offsets
     int g0;                        // global index of local group 0
+    Partial *pfull;                // [G][NM*RM*nfb] partial arg-max records of the full-superblock search (piv = -1)
+    int nfb;                       // fiber blocks per half-step launch
     const ttx_cdfseg *cdf_tab;     // [cdf_kmax+1][TTX_TABSEG] lottery CDF segments for every K (nullptr: build in-kernel)
     const int *cdf_ns;             // [cdf_kmax+1]
     int cdf_kmax;

@@ -137,7 +137,7 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     *out = nullptr;
     if (cfg->d < 2) return fail(TTX_EINVAL, "dtt_dmrgg: l,m: 1 %d", cfg->d);
     if (cfg->maxrank < 1 || cfg->maxrank > 128) return fail(TTX_EINVAL, "ttx_create: maxrank must be in 1..128 (got %d)", cfg->maxrank);
-    if (cfg->pivoting < 0) return fail(TTX_EINVAL, "dtt_dmrgg: pivoting %d (full superblock search) is not available in this build", cfg->pivoting);
+    if (cfg->pivoting < -1) return fail(TTX_EINVAL, "dtt_dmrgg: unknown pivoting: %d", cfg->pivoting);   // lib/dmrgg.f90:590-592
     if (2 * cfg->pivoting + 2 > TTX_MAXH) return fail(TTX_EINVAL, "dtt_dmrgg: pivoting %d too large", cfg->pivoting);
     if (cfg->fun_id < 1 || cfg->fun_id > 3) return fail(TTX_EINVAL, "ttx_create: unknown fun_id %d", cfg->fun_id);
     const int W = cfg->world_size < 1 ? 1 : cfg->world_size;
@@ -173,8 +173,8 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     h->nbmax = 0;
     for (int g = 0; g < nproc; g++) h->nbmax = std::max(h->nbmax, h->own[g + 1] - h->own[g]);   // same launch shape on every GPU
     h->NC = h->nbmax + 1;
-    h->mode = (cfg->pivoting == 0) ? 1 : 0;
-    h->H = (cfg->pivoting == 0) ? 2 : 2 * cfg->pivoting;
+    h->mode = (cfg->pivoting == 0) ? 1 : (cfg->pivoting < 0) ? 2 : 0;
+    h->H = (cfg->pivoting <= 0) ? 2 : 2 * cfg->pivoting;
     HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 
     DevProb &P = h->P;
@@ -213,6 +213,8 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     A_(dev_alloc(h, &P.acol, G * RM * NM)); A_(dev_alloc(h, &P.arow, G * RM * NM));
     A_(dev_alloc(h, &P.Tq, G * NC * RM * RM));
     A_(dev_alloc(h, &P.ind0, d + 2)); A_(dev_alloc(h, &P.gs, G));
+    P.nfb = (int)((RM * NM + TTX_BLK - 1) / TTX_BLK);
+    if (cfg->pivoting < 0) A_(dev_alloc(h, &P.pfull, G * NM * RM * (size_t)P.nfb));
     // exchange buffers
     P.XD = RM * NM + RM * RM;
     P.IOFF = (sizeof(int) * (XH + d + 2) + 15) & ~(size_t)15;
@@ -558,11 +560,20 @@ static int run_impl(ttx_engine *h)
         it++;
         const int dir = 2 - it % 2;
         for (int pp = 1; pp <= h->nbmax; pp++) {
-            { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp); }
-            {
+            if (h->cfg.pivoting >= 0) {
+                { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp); }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
                 for (int hh = 0; hh < h->H; hh++)
                     hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode, h->half_vals);
+            } else {
+                // full pivoting (:341-408): every superblock column through the half-step kernel, global arg-max,
+                // then the cross through the winner (evaluation only)
+                KScope ks(h, TTX_K_HALFSTEP, 5);
+                hipLaunchKernelGGL(k_bond_begin, dim3(G), dim3(64), 0, st, P, dir, pp);
+                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 3, h->half_vals);
+                hipLaunchKernelGGL(k_full_resolve, dim3(G), dim3(256), 0, st, P);
+                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 2, h->half_vals);
+                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 1, dir, 2, h->half_vals);
             }
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }

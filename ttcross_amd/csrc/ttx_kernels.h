@@ -476,6 +476,60 @@ __global__ __launch_bounds__(256) void k_init_final(DevProb P)
     if (tid == 0) { gs.pivotmax_prev = gs.amax; gs.pivotmax = -1.0; gs.pivotmin = -1.0; gs.initval = val; }
 }
 
+// snapshot of the bond this group works on at step pp of the sweep (:325-335); thread 0 only
+__device__ inline void bond_state(const DevProb &P, int g, int dir, int pp, StepState &st)
+{
+    GroupState &gs = P.gs[g];
+    const int m = P.d;
+    int *r = P.r + (size_t)g * (m + 2);
+    if (pp == 1) {                                        // sweep start, :325-327
+        gs.pivotmax = -1.0; gs.pivotmin = -1.0;
+        int *rr = P.rr + (size_t)g * (m + 2);
+        for (int s = 0; s <= m; s++) rr[s] = r[s];
+    }
+    int nb = gs.last - gs.first + 1;
+    st.active = (pp <= nb);
+    st.done = 0; st.havecol = 0; st.haverow = 0; st.crs = 0; st.pending = 0; st.pivot = 0.0;
+    st.ii = st.jj = st.kk = st.qq = 0;
+    if (st.active) {
+        int p = (dir == 1) ? gs.first + pp - 1 : gs.last + 1 - pp;   // :330-331
+        st.p = p; st.r0 = r[p - 1]; st.r1 = r[p]; st.r2 = r[p + 1]; st.n1 = P.n[p]; st.n2 = P.n[p + 1];
+    } else { st.p = 0; st.r0 = st.r1 = st.r2 = st.n1 = st.n2 = 0; st.done = 1; }
+}
+
+// full pivoting (piv = -1, :341-408): the bond state, then one column half-step per (k,q) (k_halfstep mode 3),
+// then the global first arg-max over the partial records
+__global__ void k_bond_begin(DevProb P, int dir, int pp)
+{
+    if (threadIdx.x != 0) return;
+    StepState st;
+    bond_state(P, blockIdx.x, dir, pp, st);
+    P.gs[blockIdx.x].S[0] = st;
+}
+__global__ __launch_bounds__(256) void k_full_resolve(DevProb P)
+{
+    __shared__ double sha[4], shv[4]; __shared__ int shi[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    GroupState &gs = P.gs[g];
+    StepState st = gs.S[0];
+    if (!st.active) return;
+    const int nf = st.r0 * st.n1, nb = (nf + TTX_BLK - 1) / TTX_BLK, ncol = st.n2 * st.r2;
+    double ba = -1.0, bv = 0.0; int bi = INT_MAX;
+    for (int x = tid; x < ncol * nb; x += blockDim.x) {
+        const Partial pr = P.pfull[((size_t)g * P.NM * P.RM + x / nb) * P.nfb + x % nb];
+        if (pr.absmax > ba || (pr.absmax == ba && pr.idx < bi)) { ba = pr.absmax; bv = pr.val; bi = pr.idx; }
+    }
+    block_argmax(ba, bv, bi, sha, shv, shi);
+    if (tid == 0) {                                       // :388-396
+        int x = bi;
+        st.qq = x / (nf * st.n2) + 1; x %= nf * st.n2;
+        st.kk = x / nf + 1; x %= nf;
+        st.jj = x / st.r0 + 1; st.ii = x % st.r0 + 1;
+        st.pivot = bv;
+        gs.S[0] = st;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_lottery: lottery2 candidates, their values and residuals, start pivot (lib/dmrgg.f90:410-484)
 // one block per group
@@ -492,22 +546,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
     const int g = blockIdx.x, tid = threadIdx.x, m = P.d;
     GroupState &gs = P.gs[g];
     STAMP_DECL;
-    int *r = P.r + (size_t)g * (m + 2);
-    if (tid == 0) {
-        if (pp == 1) {                                        // sweep start, :325-327
-            gs.pivotmax = -1.0; gs.pivotmin = -1.0;
-            int *rr = P.rr + (size_t)g * (m + 2);
-            for (int s = 0; s <= m; s++) rr[s] = r[s];
-        }
-        int nb = gs.last - gs.first + 1;
-        st.active = (pp <= nb);
-        st.done = 0; st.havecol = 0; st.haverow = 0; st.crs = 0; st.pending = 0; st.pivot = 0.0;
-        st.ii = st.jj = st.kk = st.qq = 0;
-        if (st.active) {
-            int p = (dir == 1) ? gs.first + pp - 1 : gs.last + 1 - pp;   // :330-331
-            st.p = p; st.r0 = r[p - 1]; st.r1 = r[p]; st.r2 = r[p + 1]; st.n1 = P.n[p]; st.n2 = P.n[p + 1];
-        } else { st.p = 0; st.r0 = st.r1 = st.r2 = st.n1 = st.n2 = 0; st.done = 1; }
-    }
+    if (tid == 0) bond_state(P, g, dir, pp, st);
     __syncthreads();
     if (!st.active) { if (tid == 0) gs.S[0] = st; return; }
     STAMP(gs, 0);   // 0: state
@@ -622,11 +661,15 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     const int g = blockIdx.y, tid = threadIdx.x, m = P.d;
     GroupState &gs = P.gs[g];
     STAMP_DECL;
-    if (tid == 0) { cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]); }
+    if (tid == 0) {
+        cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]);
+        if (mode == 3) { cur.kk = (int)blockIdx.z % cur.n2 + 1; cur.qq = (int)blockIdx.z / cur.n2 + 1; }   // :356-369 column (k,q)
+    }
     __syncthreads();
-    if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
+    if (mode == 3) { if (!cur.active || (int)blockIdx.z >= cur.n2 * cur.r2) return; }
+    else if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
     STAMP(gs, 1);   // 0: resolve
-    const bool iscol = (mode == 1) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
+    const bool iscol = (mode == 3) ? true : (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
     const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
     const int nf = iscol ? r0 * n1 : n2 * r2;
     if (blockIdx.x * TTX_BLK >= nf) return;
@@ -690,15 +733,15 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             else       { sx.pa = fxs; sx.A = p; sx.self = u + 1; sx.pb = vt + (size_t)v * VS; }
             a = eval_src3<FUN, true>(P, par, sx);                             // :520-526 / :553-559
         }
-        (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
+        if (mode != 3) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
     }
     STAMP(gs, 1);   // 2: eval
     double mx = block_max(live ? fabs(a) : 0.0, sha);
     if (tid == 0) atomic_max_pos(&gs.amax, mx);                               // :531 / :564
     const int crs = cur.crs + 1;
     const int havecol = cur.havecol | (iscol ? 1 : 0), haverow = cur.haverow | (iscol ? 0 : 1);
-    const int done = (mode == 1) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
-    const bool resid = (mode == 0) && !done;
+    const int done = (mode == 1 || mode == 2) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
+    const bool resid = (mode == 3) || ((mode == 0) && !done);
     if (resid) {
         double b = a, ab = -1.0; int bi = INT_MAX;
         if (live) {
@@ -717,14 +760,24 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
         }
         STAMP(gs, 1);   // 3: residual
         block_argmax(ab, b, bi, sha, shv, shi);
-        if (tid == 0) { Partial pr; pr.absmax = ab; pr.val = b; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][blockIdx.x] = pr; }
+        if (tid == 0) {
+            Partial pr; pr.absmax = ab; pr.val = b; pr.idx = bi; pr.pad = 0;
+            if (mode == 3) {   // superblock linear index ijkq = t + r0*n1*(column), :388-394
+                if (bi != INT_MAX) pr.idx = bi + r0 * n1 * (int)blockIdx.z;
+                P.pfull[((size_t)g * P.NM * P.RM + blockIdx.z) * P.nfb + blockIdx.x] = pr;
+            } else gs.Pt[h & 1][blockIdx.x] = pr;
+        }
+    }
+    if (mode == 3) {
+        if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) gs.neval += (long long)r0 * n1 * n2 * r2;   // :372
+        return;
     }
     if (blockIdx.x == 0 && tid == 0) {
         StepState nx = cur;
         nx.crs = crs; nx.havecol = havecol; nx.haverow = haverow; nx.done = done;
         nx.pending = resid ? (iscol ? 1 : 2) : 0;
         gs.S[h + 1] = nx;
-        gs.neval += nf;                                                       // :527 / :560 / :509
+        if (mode != 2) gs.neval += nf;                                        // :527 / :560 / :509
         // algorithmic traffic: factor slabs + vector + fiber in/out when a residual is taken, else the fiber
         gs.bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
         gs.n_resid += resid ? 1 : 0;
