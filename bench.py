@@ -183,8 +183,43 @@ def main():
     bytes_per_launch = hs["bytes"] / max(hs["launches"], 1)
     achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
 
+    # K2 in isolation on an HBM-resident factor (the same residual + arg-max code): where bandwidth, not launch
+    # latency, is the limit.  And the reference's 1-rank decomposition (1 bond group) for comparison.
+    k2 = None
+    one_group = None
+    if rank == 0 and world == 1:
+        m_rows, r_cols = 1 << 22, 32
+        ms, by = E.k_residual_bench(m_rows, r_cols, 20, device=local)
+        k2 = {"kernel": "k_resid_argmax_stream (K2 residual + arg-max, same arithmetic)", "rows": m_rows, "rank": r_cols,
+              "factor_bytes": 8 * m_rows * r_cols, "avg_launch_us": 1e3 * ms, "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS}
+        if groups != 1:
+            t1 = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
+                           nproc=1, device=local)
+            t1.run()
+            tb = time.perf_counter()
+            for _ in range(3):
+                t1.run()
+            d1 = (time.perf_counter() - tb) / 3
+            one_group = {"bond_groups": 1, "ms_per_step": 1e3 * d1, "value": t1.neval / d1, "neval_per_step": t1.neval,
+                         "integral": t1.quad(s["quad"])}
+            t1.close()
     if rank != 0:
         return
+    traffic = None
+    try:   # per-launch FETCH_SIZE + WRITE_SIZE of k_halfstep from the committed PMC passes of this same command
+        import csv
+        f = w = None
+        for row in csv.reader(l for l in open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_c64_g8.csv")) if not l.startswith("#")):
+            if len(row) >= 6 and "k_halfstep" in row[1]:
+                if row[2] == "FETCH_SIZE":
+                    f = float(row[5])
+                if row[2] == "WRITE_SIZE":
+                    w = float(row[5])
+        if f is not None and w is not None and a.workload == "c64" and groups == 8:
+            traffic = (f + w) * 1024.0
+    except Exception:  # noqa: BLE001
+        traffic = None
     out = {
         "metric": "fiber evals/s (neval / wall time of dtt_dmrgg), " + desc,
         "value": neval / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -194,11 +229,15 @@ def main():
                    "neval_per_step": neval // a.steps, "sweeps": nsweeps, "integral": value,
                    "rel_err_vs_analytic": abs(1 - value / s["tru"]) if s["tru"] else None},
         "roofline": {"kernel": "k_halfstep (fiber evaluation + residual + arg-max)", "bound": "hbm", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_us": avg_us, "launches_per_step": hs["launches"] / max(1, min(a.steps, 3)),
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "kernel_ms_per_step": {k: v["ms"] / max(1, min(a.steps, 3)) for k, v in agg.items()},
     }
+    if k2:
+        out["k2_streaming"] = k2
+    if one_group:
+        out["single_group"] = one_group
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(argv)
     print(json.dumps(out))

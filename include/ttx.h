@@ -126,6 +126,10 @@ int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double
  * b = a - F*x in netlib dgemv order, F = m x r column-major (ld m); returns 0-based argmax and b[argmax]. */
 int ttx_k_residual_argmax(int32_t device, int32_t m, int32_t r, const double *a, const double *F, const double *x,
                           double *b_out, int32_t *imax, double *bmax);
+/* K2 streaming benchmark: the same residual + arg-max kernel on a synthetic m x r factor resident in HBM
+ * (m*r*8 bytes, generated on the device); returns the average kernel time over `iters` launches measured with
+ * HIP events, and the algorithmic bytes 8*(m*r + r + 2*m) one launch moves. */
+int ttx_k_residual_bench(int32_t device, int64_t m, int32_t r, int32_t iters, double *avg_ms, double *bytes);
 /* K1: batch integrand evaluation, ind = npts x d (row-major, 1-based indices) */
 int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
                const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out);

@@ -766,6 +766,36 @@ extern "C" int ttx_k_residual_argmax(int32_t device, int32_t m, int32_t r, const
     return TTX_OK;
 }
 
+extern "C" int ttx_k_residual_bench(int32_t device, int64_t m, int32_t r, int32_t iters, double *avg_ms, double *bytes)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "no HIP device");
+    HIPCHECK(hipSetDevice(device));
+    if (m < 1 || m > 2000000000LL || r < 1 || r > 256 || iters < 1) return fail(TTX_EINVAL, "ttx_k_residual_bench: bad sizes");
+    double *da, *dF, *dx, *db; Partial *dp;
+    const int nb = 256 * 8;                                 // 8 blocks per CU, grid-stride
+    HIPCHECK(hipMalloc((void **)&da, sizeof(double) * m)); HIPCHECK(hipMalloc((void **)&dF, sizeof(double) * (size_t)m * r));
+    HIPCHECK(hipMalloc((void **)&dx, sizeof(double) * r)); HIPCHECK(hipMalloc((void **)&db, sizeof(double) * m));
+    HIPCHECK(hipMalloc((void **)&dp, sizeof(Partial) * nb));
+    hipLaunchKernelGGL(k_fill_synth, dim3(2048), dim3(256), 0, 0, da, (size_t)m, 1ull);
+    hipLaunchKernelGGL(k_fill_synth, dim3(2048), dim3(256), 0, 0, dF, (size_t)m * r, 2ull);
+    hipLaunchKernelGGL(k_fill_synth, dim3(1), dim3(256), 0, 0, dx, (size_t)r, 3ull);
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_resid_argmax_stream, dim3(nb), dim3(TTX_BLK), 0, 0, (long long)m, r, (size_t)m, da, dF, dx, db, dp);
+    HIPCHECK(hipEventRecord(e0, 0));
+    for (int w = 0; w < iters; w++) hipLaunchKernelGGL(k_resid_argmax_stream, dim3(nb), dim3(TTX_BLK), 0, 0, (long long)m, r, (size_t)m, da, dF, dx, db, dp);
+    HIPCHECK(hipEventRecord(e1, 0));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    *bytes = 8.0 * ((double)m * r + r + 2.0 * m);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(da); (void)hipFree(dF); (void)hipFree(dx); (void)hipFree(db); (void)hipFree(dp);
+    return TTX_OK;
+}
+
 extern "C" int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
                           const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out)
 {

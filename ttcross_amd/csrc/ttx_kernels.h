@@ -1338,3 +1338,31 @@ __global__ void k_collect(DevProb P)
     o[SUM_NEVAL] = nev; o[SUM_BYTES] = by; o[SUM_NRESID] = nr;
     if (P.g0 == 0) o[SUM_VAL] = P.gs[0].val;     // identical on every GPU; contributed once
 }
+
+__global__ void k_fill_synth(double *p, size_t n, unsigned long long seed)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ull + seed; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        p[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+// grid-stride variant of k_resid_argmax for factors far larger than one wave of blocks (same arithmetic per row)
+__global__ __launch_bounds__(TTX_BLK) void k_resid_argmax_stream(long long m, int r, size_t ld, const double *a, const double *F, const double *x,
+                                                                 double *b_out, Partial *parts)
+{
+    __shared__ double xs[256];
+    __shared__ double sha[4], shv[4]; __shared__ int shi[4];
+    for (int s = threadIdx.x; s < r; s += TTX_BLK) xs[s] = x[s];
+    __syncthreads();
+    double ab = -1.0, bv = 0.0; int bi = INT_MAX;
+    for (long long t = (long long)blockIdx.x * TTX_BLK + threadIdx.x; t < m; t += (long long)gridDim.x * TTX_BLK) {
+        double b = a[t];
+#pragma unroll 8
+        for (int s = 0; s < r; s++) b = b + (-xs[s]) * F[t + ld * s];
+        b_out[t] = b;
+        double aa = fabs(b);
+        if (aa > ab || (aa == ab && (int)t < bi)) { ab = aa; bv = b; bi = (int)t; }
+    }
+    block_argmax(ab, bv, bi, sha, shv, shi);
+    if (threadIdx.x == 0) { Partial pr; pr.absmax = ab; pr.val = bv; pr.idx = bi; pr.pad = 0; parts[blockIdx.x] = pr; }
+}

@@ -85,6 +85,7 @@ def load_library():
     L.ttx_kernel_stats.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
     L.ttx_k_residual_argmax.argtypes = [c_int32, c_int32, c_int32, POINTER(c_double), POINTER(c_double),
                                         POINTER(c_double), POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
+    L.ttx_k_residual_bench.argtypes = [c_int32, c_int64, c_int32, c_int32, POINTER(c_double), POINTER(c_double)]
     L.ttx_k_eval.argtypes = [c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_double), c_int32,
                              POINTER(c_double), c_int32, c_int64, POINTER(c_int32), POINTER(c_double)]
     L.ttx_k_lottery.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),
@@ -285,6 +286,13 @@ def k_residual_argmax(a, F, x, device=0):
     _check(load_library().ttx_k_residual_argmax(device, m, r, _dp(a), F.ctypes.data_as(POINTER(c_double)), _dp(x), _dp(b),
                                                 ctypes.byref(im), ctypes.byref(bm)))
     return b, im.value, bm.value
+
+
+def k_residual_bench(m, r, iters=20, device=0):
+    """(avg kernel ms, algorithmic bytes) of the K2 residual + arg-max kernel on an m x r factor in HBM."""
+    ms, by = c_double(), c_double()
+    _check(load_library().ttx_k_residual_bench(device, m, r, iters, ctypes.byref(ms), ctypes.byref(by)))
+    return ms.value, by.value
 
 
 def k_eval(fun_id, n, par, ind, aux=None, device=0):
