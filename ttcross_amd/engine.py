@@ -107,6 +107,52 @@ def _ip(a):
     return a.ctypes.data_as(POINTER(c_int32)) if a is not None else None
 
 
+def split_groups(nproc, world_rank, world_size):
+    """Bond groups [g0, g0+G) held by one process: contiguous deal, as ttx_create does (include/ttx.h, nproc/world_size)."""
+    g0 = nproc * world_rank // world_size
+    return g0, nproc * (world_rank + 1) // world_size - g0
+
+
+def neighbour_ranks(nproc, world_rank, world_size):
+    """(left, right) process ranks the boundary groups exchange with; -1 where the chain ends."""
+    g0, G = split_groups(nproc, world_rank, world_size)
+    return (world_rank - 1 if g0 > 0 else -1), (world_rank + 1 if g0 + G < nproc else -1)
+
+
+def make_dist_transport(dist, group=None):
+    """ctypes thunks (sendrecv, allreduce) of include/ttx.h's ttx_transport over torch.distributed CPU tensors."""
+    import torch
+
+    def _t(ptr, nbytes):
+        return torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.uint8)
+
+    def sendrecv(ctx, to, sbuf, ns, frm, rbuf, nr):
+        try:
+            ops = []
+            if to >= 0:
+                ops.append(dist.P2POp(dist.isend, _t(sbuf, ns), to, group))
+            if frm >= 0:
+                ops.append(dist.P2POp(dist.irecv, _t(rbuf, nr), frm, group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("transport sendrecv failed:", e, flush=True)
+            return 1
+
+    def allreduce(ctx, buf, count, op):
+        try:
+            t = torch.frombuffer((ctypes.c_double * count).from_address(ctypes.addressof(buf.contents)), dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("transport allreduce failed:", e, flush=True)
+            return 1
+
+    return _SENDRECV(sendrecv), _ALLREDUCE(allreduce)
+
+
 class TTCross:
     """One dtt_dmrgg problem resident on one MI355X (the `type(dtt) :: arg` of the reference plus the
     sweep state).  n: mode sizes arg%n(1:d); quad: list/array of per-mode weight vectors (rank-1 TT)."""
@@ -170,36 +216,7 @@ class TTCross:
     def set_dist_transport(self, dist, group=None):
         """Host-callback transport over torch.distributed CPU tensors (gloo): used where RCCL cannot run
         (several ranks on one GPU) -- same engine code path, messages staged through pinned host memory."""
-        import torch
-
-        def _t(ptr, nbytes):
-            return torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.uint8)
-
-        def sendrecv(ctx, to, sbuf, ns, frm, rbuf, nr):
-            try:
-                ops = []
-                if to >= 0:
-                    ops.append(dist.P2POp(dist.isend, _t(sbuf, ns), to, group))
-                if frm >= 0:
-                    ops.append(dist.P2POp(dist.irecv, _t(rbuf, nr), frm, group))
-                if ops:
-                    for w in dist.batch_isend_irecv(ops):
-                        w.wait()
-                return 0
-            except Exception as e:  # noqa: BLE001
-                print("transport sendrecv failed:", e, flush=True)
-                return 1
-
-        def allreduce(ctx, buf, count, op):
-            try:
-                t = torch.frombuffer((ctypes.c_double * count).from_address(ctypes.addressof(buf.contents)), dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM, group=group)
-                return 0
-            except Exception as e:  # noqa: BLE001
-                print("transport allreduce failed:", e, flush=True)
-                return 1
-
-        self._cb = (_SENDRECV(sendrecv), _ALLREDUCE(allreduce))       # keep the thunks alive
+        self._cb = make_dist_transport(dist, group)                   # keep the thunks alive
         tr = _Transport(None, self._cb[0], self._cb[1])
         _check(load_library().ttx_set_transport(self._h, ctypes.byref(tr)))
 
