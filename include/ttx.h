@@ -108,6 +108,12 @@ int ttx_get_core(const ttx_engine *h, int k, double *buf);        /* arg%u(k)%p,
 /* dtt_quad(arg, quad) on the finalised cores (lib/dmrgg.f90:1261-1415); w = d blocks of n[k] weights, NULL = sum */
 int ttx_quad(ttx_engine *h, const double *w, double *val);
 
+/* dtt_accchk(nlot, arg, einf, efro, ainf, afro, fun, par, pivot), lib/dmrgg.f90:1081-1166: nlot random samples of
+ * |fun - TT| drawn from the run-time RNG stream where dtt_dmrgg left it (irnd, lib/rnd.f90:83-88); element
+ * evaluation as dtt_ijk (lib/tt.f90:630-652).  Single-process engines only (as in the reference, every rank
+ * would need all cores).  pivot: d ints (worst sample) or NULL. */
+int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efro, double *ainf, double *afro, int32_t *pivot);
+
 /* profiling: with on != 0 the next ttx_run brackets every kernel launch with HIP events on the engine's
  * stream; ttx_kernel_stats then reports, per kernel kind, launches and total milliseconds. */
 #define TTX_K_LOTTERY 0

@@ -1035,6 +1035,7 @@ int ttxo_dmrgg(const ttxo_problem *pb, ttxo_result *res)
     /* :1029 finalise */
     dtt_lua_all(cx, targ, 0);
     res->neval = nevalall;
+    res->rngpos = cx->rk[0].rngpos;
     clock_gettime(CLOCK_MONOTONIC, &ts1);
     res->seconds = (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
 
@@ -1067,6 +1068,41 @@ int ttxo_dmrgg(const ttxo_problem *pb, ttxo_result *res)
     }
     free(ttqq); free(targ); free(cx->rk); free(cx->own); free(shifts);
     return 0;
+}
+
+/* lib/dmrgg.f90:1081-1166 (nproc = 1) */
+void ttxo_accchk(const ttxo_problem *pb, const ttxo_result *res, int nlot, double *einf, double *efro, double *ainf,
+                 double *afro, int32_t *pivot)
+{
+    const int m = pb->d;
+    uint64_t pos = res->rngpos;
+    int32_t ind[2050];
+    double e1 = 0.0, e2 = 0.0, a1 = 0.0, a2 = 0.0;
+    double *x = (double *)malloc(sizeof(double) * 4096), *z = (double *)malloc(sizeof(double) * 4096);
+    for (int il = 0; il < nlot; il++) {
+        for (int i = 0; i < m; i++) { double d = pb->draws ? pb->draws[pos] : ttxo_flang_draw(pos); pos++; ind[i] = (int)(d * pb->n[i]) + 1; }   /* irnd */
+        double aval = ttxo_fun(pb->fun_id, m, ind, pb->n, pb->par, pb->aux);
+        /* dtt_ijk: x = U_m(:, ind_m, 1); for i = m-1..1: x = U_i(:, ind_i, :) * x */
+        int r0 = res->r[m - 1], r1 = res->r[m];
+        for (int t = 0; t < r0; t++) x[t] = res->cores[m - 1][t + (size_t)r0 * ((ind[m - 1] - 1) + (size_t)pb->n[m - 1] * 0)];
+        (void)r1;
+        for (int i = m - 1; i >= 1; i--) {
+            int q0 = res->r[i - 1], q1 = res->r[i], n = pb->n[i - 1];
+            for (int t = 0; t < q0; t++) {
+                double s = 0.0;
+                for (int k = 0; k < q1; k++) s = s + res->cores[i - 1][t + (size_t)q0 * ((ind[i - 1] - 1) + (size_t)n * k)] * x[k];
+                z[t] = s;
+            }
+            memcpy(x, z, sizeof(double) * (size_t)q0);
+        }
+        double bval = x[0];
+        if (e1 < fabs(aval - bval)) { e1 = fabs(aval - bval); if (pivot) memcpy(pivot, ind, sizeof(int32_t) * (size_t)m); }
+        e2 = e2 + (aval - bval) * (aval - bval);
+        a1 = fmax(a1, aval);
+        a2 = a2 + aval * aval;
+    }
+    *einf = e1; *ainf = a1; *efro = sqrt(e2); *afro = sqrt(a2);
+    free(x); free(z);
 }
 
 void ttxo_free_result(ttxo_result *res)

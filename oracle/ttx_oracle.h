@@ -72,12 +72,17 @@ typedef struct ttxo_result {
     int64_t neval;
     double value;              /* dtt_quad(tt, qq) after finalisation (0 when no quad)               */
     double seconds;            /* wall time of the dmrgg call                                        */
+    uint64_t rngpos;           /* uniform draws consumed by rank 0 (position of the run-time RNG stream) */
 } ttxo_result;
 
 /* lib/dmrgg.f90:11-1050 (+ lib/dmrggmp.f90:572-629 for the right-going boundary exchange). */
 int ttxo_dmrgg(const ttxo_problem *prob, ttxo_result *res);
 void ttxo_free_result(ttxo_result *res);
 
+/* lib/dmrgg.f90:1081-1166 dtt_accchk on the finalised cores of `res` (1 rank): nlot random samples drawn from
+ * the same run-time RNG stream (irnd, lib/rnd.f90:83-88), element evaluation dtt_ijk (lib/tt.f90:630-652) */
+void ttxo_accchk(const ttxo_problem *prob, const ttxo_result *res, int nlot, double *einf, double *efro, double *ainf,
+                 double *afro, int32_t *pivot);
 /* lib/quad.f90:97-131 */
 void ttxo_lgwt(int n, double *x, double *w);
 /* lib/default.f90:78-97 */

@@ -39,3 +39,8 @@ program rng
 end program
 F
 amdflang -O2 /tmp/ttx_rng.f90 -o /tmp/ttx_rng.exe -Wl,-rpath,/opt/rocm/lib/llvm/lib && /tmp/ttx_rng.exe > $G/flang_rng.txt
+# dtt_accchk (lib/dmrgg.f90:1081) of the genuine reference through a small driver of our own
+amdflang -O2 -fopenmp -I/opt/conda/include -Ioracle/_ref/mod tests/golden/ref_accchk.f90 oracle/_ref/obj/{zero,nan,trans,default,timef,say,rnd,ptype,ort,lr,mat,quad,tt,dmrgg,mvn_pdf}.o \
+  -o oracle/_ref/ref_accchk -L/opt/conda/lib -lmpifort -lmpi -lmkl_rt -Wl,-rpath,/opt/conda/lib -Wl,-rpath,/opt/rocm/lib/llvm/lib 2>/dev/null
+oracle/_ref/ref_accchk 6 33 12 2 2000 | grep -E "accchk|pivot" > $G/accchk_C_6_33_12_2_2000.txt
+oracle/_ref/ref_accchk 8 25 10 3 5000 | grep -E "accchk|pivot" > $G/accchk_C_8_25_10_3_5000.txt

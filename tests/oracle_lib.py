@@ -24,7 +24,7 @@ class _Problem(ctypes.Structure):
 class _Result(ctypes.Structure):
     _fields_ = [("d", c_int32), ("nsweeps", c_int32), ("sweeps", POINTER(_Rec)), ("tapes", POINTER(c_int32)),
                 ("r", POINTER(c_int32)), ("cores", POINTER(POINTER(c_double))), ("neval", c_int64), ("value", c_double),
-                ("seconds", c_double)]
+                ("seconds", c_double), ("rngpos", c_uint64)]
 
 
 _lib = None
@@ -56,7 +56,7 @@ def _ip(a):
     return a.ctypes.data_as(POINTER(c_int32)) if a is not None else None
 
 
-def dmrgg(n, fun_id, par, maxrank, piv=3, accuracy=None, quad=None, tru=None, aux=None, nproc=1, mybonds=None):
+def dmrgg(n, fun_id, par, maxrank, piv=3, accuracy=None, quad=None, tru=None, aux=None, nproc=1, mybonds=None, accchk=0):
     L = lib()
     n = np.ascontiguousarray(n, dtype=np.int32)
     par = np.ascontiguousarray(par, dtype=np.float64)
@@ -87,7 +87,16 @@ def dmrgg(n, fun_id, par, maxrank, piv=3, accuracy=None, quad=None, tru=None, au
     for k in range(d):
         sz = int(r[k]) * int(n[k]) * int(r[k + 1])
         cores.append(np.ctypeslib.as_array(res.cores[k], shape=(sz,)).copy().reshape((r[k], n[k], r[k + 1]), order="F"))
-    out = dict(sweeps=sweeps, tapes=tapes, r=r, cores=cores, neval=int(res.neval), value=float(res.value), seconds=float(res.seconds))
+    out = dict(sweeps=sweeps, tapes=tapes, r=r, cores=cores, neval=int(res.neval), value=float(res.value), seconds=float(res.seconds),
+               rngpos=int(res.rngpos))
+    if accchk:
+        L.ttxo_accchk.argtypes = [POINTER(_Problem), POINTER(_Result), ctypes.c_int, POINTER(c_double), POINTER(c_double),
+                                  POINTER(c_double), POINTER(c_double), POINTER(c_int32)]
+        L.ttxo_accchk.restype = None
+        e1, e2, a1, a2 = c_double(), c_double(), c_double(), c_double()
+        piv_ = np.zeros(d, dtype=np.int32)
+        L.ttxo_accchk(ctypes.byref(pb), ctypes.byref(res), accchk, ctypes.byref(e1), ctypes.byref(e2), ctypes.byref(a1), ctypes.byref(a2), _ip(piv_))
+        out["accchk"] = dict(einf=e1.value, efro=e2.value, ainf=a1.value, afro=a2.value, pivot=piv_)
     L.ttxo_free_result(ctypes.byref(res))
     return out
 

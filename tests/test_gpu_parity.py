@@ -172,3 +172,26 @@ def test_fortran_dropin_driver_matches_reference_log(name):
         assert a["it"] == b["it"] and a["dir"] == b["dir"] and a["erank"] == b["erank"] and a["neval"] == b["neval"]
         assert abs(a["val"] - b["val"]) <= 2e-13 * abs(a["val"])
     assert abs(g_val - o_val) <= 1e-14 * abs(g_val)
+
+
+@pytest.mark.parametrize("m,n,r,piv,nlot,ng", [(6, 33, 12, 2, 2000, 1), (8, 25, 10, 3, 5000, 1), (8, 25, 10, 3, 1500, 3)])
+def test_accchk(m, n, r, piv, nlot, ng):
+    """dtt_accchk (A14): the engine vs the oracle (same RNG stream position, same samples; the per-sample values are
+    bit-identical so einf, ainf and the worst index must match exactly; the two Frobenius sums are accumulated
+    in sample order on the host) and vs the GENUINE reference's output (tests/golden/accchk_*.txt)."""
+    import os
+    from golden_util import GOLDEN
+    s = D.ising_setup("c", m, n)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], nproc=ng).run()
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], nproc=ng, accchk=nlot)
+    g, o = tt.accchk(nlot), oo["accchk"]
+    assert g["einf"] == o["einf"] and g["ainf"] == o["ainf"] and np.array_equal(g["pivot"], o["pivot"])
+    assert g["efro"] == o["efro"] and g["afro"] == o["afro"]
+    f = os.path.join(GOLDEN, f"accchk_C_{m}_{n}_{r}_{piv}_{nlot}.txt")
+    if ng == 1 and os.path.exists(f):
+        lines = open(f).read().split("\n")
+        ref = [float(x) for x in lines[0].split()[1:]]
+        refpiv = [int(x) for x in lines[1].split()[1:]]
+        assert list(g["pivot"]) == refpiv
+        assert g["ainf"] == ref[2] and abs(g["afro"] - ref[3]) <= 1e-14 * ref[3]
+        assert abs(g["einf"] - ref[0]) <= 1e-6 * ref[0] and abs(g["efro"] - ref[1]) <= 1e-6 * ref[1]

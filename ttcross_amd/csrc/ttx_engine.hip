@@ -731,6 +731,55 @@ extern "C" int ttx_quad(ttx_engine *h, const double *w, double *val)
     return TTX_OK;
 }
 
+template <int FUN>
+static int accchk_impl(ttx_engine *h, int nlot, double *einf, double *efro, double *ainf, double *afro, int32_t *pivot)
+{
+    DevProb &P = h->P;
+    const int d = h->d;
+    std::vector<int> owner(d + 2, 0);
+    for (int k = 1; k <= d; k++) owner[k] = owner_of_core(h, k);
+    // the stream position where dtt_dmrgg left the run-time generator (rank 0 of the reference = group 0)
+    GroupState g0s;
+    HIPCHECK(hipMemcpy(&g0s, P.gs, sizeof(GroupState), hipMemcpyDeviceToHost));
+    int *downer, *dind; double *dout;
+    HIPCHECK(hipMalloc((void **)&downer, sizeof(int) * (d + 2))); HIPCHECK(hipMalloc((void **)&dind, sizeof(int) * (size_t)nlot * d));
+    HIPCHECK(hipMalloc((void **)&dout, sizeof(double) * 4 * (size_t)nlot));
+    HIPCHECK(hipMemcpy(downer, owner.data(), sizeof(int) * (d + 2), hipMemcpyHostToDevice));
+    size_t lds = sizeof(double) * (h->par.size() + 2 * h->RM + 4) + sizeof(int) * (d + 4);
+    hipLaunchKernelGGL(k_accchk<FUN>, dim3(nlot), dim3(64), lds, h->stream, P, (unsigned long long)g0s.rngpos, nlot, (const int *)downer, dout, dind);
+    std::vector<double> o(4 * (size_t)nlot);
+    std::vector<int> ind((size_t)nlot * d);
+    HIPCHECK(hipMemcpyAsync(o.data(), dout, sizeof(double) * o.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(ind.data(), dind, sizeof(int) * ind.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipGetLastError());
+    // the reference's sequential bookkeeping over the samples (:1126-1133): strict '<' keeps the first worst sample
+    double e1 = 0.0, e2 = 0.0, a1 = 0.0, a2 = 0.0; int worst = -1;
+    for (int il = 0; il < nlot; il++) {
+        if (e1 < o[4 * (size_t)il]) { e1 = o[4 * (size_t)il]; worst = il; }
+        e2 = e2 + o[4 * (size_t)il + 1];
+        a1 = std::max(a1, o[4 * (size_t)il + 2]);
+        a2 = a2 + o[4 * (size_t)il + 3];
+    }
+    *einf = e1; *efro = std::sqrt(e2); *ainf = a1; *afro = std::sqrt(a2);
+    if (pivot && worst >= 0) for (int i = 0; i < d; i++) pivot[i] = ind[(size_t)worst * d + i];
+    (void)hipFree(downer); (void)hipFree(dind); (void)hipFree(dout);
+    return TTX_OK;
+}
+
+extern "C" int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efro, double *ainf, double *afro, int32_t *pivot)
+{
+    if (!h || !einf || !efro || !ainf || !afro || !h->ran) return fail(TTX_ESTATE, "ttx_accchk: run first");
+    if (h->W > 1) return fail(TTX_EINVAL, "dtt_accchk: every rank needs all cores; single-process engines only");
+    if (nlot < 1) return fail(TTX_EINVAL, "dtt_accchk: nlot must be positive");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    switch (h->cfg.fun_id) {
+        case TTX_FUN_ISING: return accchk_impl<FUN_ISING>(h, nlot, einf, efro, ainf, afro, pivot);
+        case TTX_FUN_STDNORM: return accchk_impl<FUN_STDNORM>(h, nlot, einf, efro, ainf, afro, pivot);
+        default: return accchk_impl<FUN_MVN>(h, nlot, einf, efro, ainf, afro, pivot);
+    }
+}
+
 extern "C" int ttx_set_profile(ttx_engine *h, int on) { if (!h) return fail(TTX_EINVAL, "null"); h->profile = on != 0; return TTX_OK; }
 extern "C" int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double ms[TTX_K_NKINDS], double bytes[TTX_K_NKINDS])
 {

@@ -1366,3 +1366,51 @@ __global__ __launch_bounds__(TTX_BLK) void k_resid_argmax_stream(long long m, in
     block_argmax(ab, bv, bi, sha, shv, shi);
     if (threadIdx.x == 0) { Partial pr; pr.absmax = ab; pr.val = bv; pr.idx = bi; pr.pad = 0; parts[blockIdx.x] = pr; }
 }
+
+// ------------------------------------------------------------------------------------------------
+// dtt_accchk (lib/dmrgg.f90:1081-1166): one wave per random sample.  out[4*il..] = (|aval-bval|, (aval-bval)^2,
+// aval, aval^2); ind_out[il*d..] = the sample's multi-index
+// ------------------------------------------------------------------------------------------------
+template <int FUN>
+__global__ __launch_bounds__(64) void k_accchk(DevProb P, unsigned long long rngpos, int nlot, const int *owner, double *out, int *ind_out)
+{
+    extern __shared__ __align__(16) double dyn[];
+    const int il = blockIdx.x, tid = threadIdx.x, m = P.d;
+    double *par = dyn, *x = dyn + ((P.npar + 1) & ~1), *z = x + P.RM;
+    int *ind = (int *)(z + P.RM);
+    for (int s = tid; s < P.npar; s += 64) par[s] = P.par[s];
+    for (int i = tid; i < m; i += 64) {                      // irnd: int(d*maxi)+1, draws in sample-major order (:1119-1122)
+        double d = ttx_flang_draw(rngpos + (unsigned long long)il * m + i);
+        ind[i] = (int)(d * P.n[i + 1]) + 1;
+        ind_out[(size_t)il * m + i] = ind[i];
+    }
+    __syncthreads();
+    double aval = 0.0;
+    if (tid == 0) { ListIdx ix{ind}; aval = eval_fun<FUN>(P, par, ix); }
+    // dtt_ijk (lib/tt.f90:630-652): x = U_m(:, ind_m, 1); for i = m-1..1: x = U_i(:, ind_i, :) x
+    {
+        const int g = owner[m], first = P.gs[g].first;
+        const int *r = P.r + (size_t)g * (m + 2);
+        const double *A = core_ptr(P, P.arg, g, m, first);
+        if (tid < r[m - 1]) x[tid] = A[tid + (size_t)P.RM * (ind[m - 1] - 1)];
+    }
+    __syncthreads();
+    for (int i = m - 1; i >= 1; i--) {
+        const int g = owner[i], first = P.gs[g].first;
+        const int *r = P.r + (size_t)g * (m + 2);
+        const int q0 = r[i - 1], q1 = r[i];
+        const double *A = core_ptr(P, P.arg, g, i, first) + (size_t)P.RM * (ind[i - 1] - 1);
+        for (int t = tid; t < q0; t += 64) {
+            double s = 0.0;
+            for (int k = 0; k < q1; k++) s = s + A[t + P.SS * k] * x[k];
+            z[t] = s;
+        }
+        __syncthreads();
+        for (int t = tid; t < q0; t += 64) x[t] = z[t];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double bval = x[0], e = aval - bval;
+        out[4 * (size_t)il] = fabs(e); out[4 * (size_t)il + 1] = e * e; out[4 * (size_t)il + 2] = aval; out[4 * (size_t)il + 3] = aval * aval;
+    }
+}

@@ -82,6 +82,7 @@ def load_library():
     L.ttx_get_core.argtypes = [c_void_p, ctypes.c_int, POINTER(c_double)]
     L.ttx_quad.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
     L.ttx_set_profile.argtypes = [c_void_p, ctypes.c_int]
+    L.ttx_accchk.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int32)]
     L.ttx_kernel_stats.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
     L.ttx_k_residual_argmax.argtypes = [c_int32, c_int32, c_int32, POINTER(c_double), POINTER(c_double),
                                         POINTER(c_double), POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
@@ -272,6 +273,13 @@ class TTCross:
         wa = None if w is None else np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.float64).ravel() for q in w]))
         _check(load_library().ttx_quad(self._h, _dp(wa), ctypes.byref(v)))
         return v.value
+
+    def accchk(self, nlot):
+        """dtt_accchk (lib/dmrgg.f90:1081): dict(einf, efro, ainf, afro, pivot) from nlot random samples."""
+        e1, e2, a1, a2 = c_double(), c_double(), c_double(), c_double()
+        pv = np.zeros(self.d, dtype=np.int32)
+        _check(load_library().ttx_accchk(self._h, nlot, ctypes.byref(e1), ctypes.byref(e2), ctypes.byref(a1), ctypes.byref(a2), _ip(pv)))
+        return dict(einf=e1.value, efro=e2.value, ainf=a1.value, afro=a2.value, pivot=pv)
 
     def kernel_stats(self):
         n = (c_int64 * 6)()

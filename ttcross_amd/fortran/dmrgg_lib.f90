@@ -91,6 +91,20 @@ contains
   val=v
  end function
 
+ subroutine dtt_accchk(nlot,arg,einf,efro,ainf,afro,fun,par,pivot)
+  ! lib/dmrgg.f90:1081: random-sample error of the TT held by the engine against the integrand it was built from
+  integer,intent(in) :: nlot
+  type(dtt),intent(in) :: arg
+  double precision,intent(out) :: einf,efro,ainf,afro
+  double precision,external :: fun
+  double precision,intent(inout),optional :: par(*)
+  integer,intent(out),optional :: pivot(tt_size)
+  integer(c_int32_t) :: pv(tt_size)
+  if(.not.c_associated(arg%ttx))then;write(*,*)'dtt_accchk: tensor train is not resident on the device (call dtt_dmrgg first)';stop;endif
+  call ttx_check(ttx_accchk(arg%ttx,int(nlot,c_int32_t),einf,efro,ainf,afro,pv),'dtt_accchk')
+  if(present(pivot))pivot(1:arg%m)=pv(1:arg%m)
+ end subroutine
+
  subroutine identify(fun,m,n,par,fid,npar,aux)
   ! which built-in integrand is `fun`?  compare values at a few probe indices
   use mvn_pdf_mod

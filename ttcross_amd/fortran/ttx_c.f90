@@ -54,6 +54,10 @@ module ttx_c
   function ttx_quad(h,w,val) bind(C,name='ttx_quad') result(rc)
    import; type(c_ptr),value :: h; type(c_ptr),value :: w; real(c_double),intent(out) :: val; integer(c_int) :: rc
   end function
+ function ttx_accchk(h,nlot,einf,efro,ainf,afro,pivot) bind(C,name='ttx_accchk') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int32_t),value :: nlot; real(c_double),intent(out) :: einf,efro,ainf,afro
+   integer(c_int32_t),intent(out) :: pivot(*); integer(c_int) :: rc
+  end function
  end interface
 contains
  subroutine ttx_check(rc,who)
