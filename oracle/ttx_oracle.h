@@ -83,6 +83,16 @@ void ttxo_free_result(ttxo_result *res);
  * the same run-time RNG stream (irnd, lib/rnd.f90:83-88), element evaluation dtt_ijk (lib/tt.f90:630-652) */
 void ttxo_accchk(const ttxo_problem *prob, const ttxo_result *res, int nlot, double *einf, double *efro, double *ainf,
                  double *afro, int32_t *pivot);
+/* tt_lib utilities on a TT with compact column-major cores (oracle/ttx_oracle_tt.c): dtt_ort lib/tt.f90:130,
+ * dtt_svd :307 (tol, rmax <= 0: absent), dtt_norm :1074 (tol < 0: absent), dtt_dot :1155, dtt_ijk :630 */
+typedef struct ttxo_tt { int32_t d; int32_t *n; int32_t *r; double **cores; } ttxo_tt;   /* n[d], r[d+1], cores[d] (malloc'd) */
+void ttxo_tt_ort(ttxo_tt *t);
+void ttxo_tt_svd(ttxo_tt *t, double tol, int rmax);
+double ttxo_tt_norm(const ttxo_tt *t, double tol);
+double ttxo_tt_dot(const ttxo_tt *x, const ttxo_tt *y);
+double ttxo_tt_ijk(const ttxo_tt *t, const int32_t *ind);
+ttxo_tt *ttxo_tt_new(int d, const int32_t *n, const int32_t *r);
+void ttxo_tt_free(ttxo_tt *b);
 /* lib/quad.f90:97-131 */
 void ttxo_lgwt(int n, double *x, double *w);
 /* lib/default.f90:78-97 */

@@ -44,3 +44,9 @@ amdflang -O2 -fopenmp -I/opt/conda/include -Ioracle/_ref/mod tests/golden/ref_ac
   -o oracle/_ref/ref_accchk -L/opt/conda/lib -lmpifort -lmpi -lmkl_rt -Wl,-rpath,/opt/conda/lib -Wl,-rpath,/opt/rocm/lib/llvm/lib 2>/dev/null
 oracle/_ref/ref_accchk 6 33 12 2 2000 | grep -E "accchk|pivot" > $G/accchk_C_6_33_12_2_2000.txt
 oracle/_ref/ref_accchk 8 25 10 3 5000 | grep -E "accchk|pivot" > $G/accchk_C_8_25_10_3_5000.txt
+# tt_lib utilities (ort / svd / norm / dot / tijk) of the genuine reference through a small driver of our own
+amdflang -O2 -fopenmp -I/opt/conda/include -Ioracle/_ref/mod tests/golden/ref_ttops.f90 oracle/_ref/obj/{zero,nan,trans,default,timef,say,rnd,ptype,ort,lr,mat,quad,tt,dmrgg,mvn_pdf}.o \
+  -o oracle/_ref/ref_ttops -L/opt/conda/lib -lmpifort -lmpi -lmkl_rt -Wl,-rpath,/opt/conda/lib -Wl,-rpath,/opt/rocm/lib/llvm/lib 2>/dev/null
+oracle/_ref/ref_ttops 6 33 12 2 | grep -vE "n_evals" > $G/ttops_C_6_33_12_2.txt
+oracle/_ref/ref_ttops 10 25 16 2 | grep -vE "n_evals" > $G/ttops_C_10_25_16_2.txt
+rm -f *.mod

@@ -129,3 +129,66 @@ def mvn_init(d):
     aux = np.zeros(d + d * d + 1)
     lib().ttxo_mvn_init(d, 0.0, 1.0, _dp(aux))
     return aux
+
+
+# ---- tt_lib utilities (oracle/ttx_oracle_tt.c) -------------------------------------------------------------
+class _TT(ctypes.Structure):
+    _fields_ = [("d", c_int32), ("n", POINTER(c_int32)), ("r", POINTER(c_int32)), ("cores", POINTER(POINTER(c_double)))]
+
+
+class OracleTT:
+    """A TT on the C heap of the oracle; cores in/out as Fortran-ordered (r0, n, r1) numpy arrays."""
+
+    def __init__(self, cores):
+        L = lib()
+        L.ttxo_tt_new.restype = POINTER(_TT)
+        L.ttxo_tt_new.argtypes = [c_int32, POINTER(c_int32), POINTER(c_int32)]
+        L.ttxo_tt_free.argtypes = [POINTER(_TT)]
+        L.ttxo_tt_ort.argtypes = [POINTER(_TT)]
+        L.ttxo_tt_svd.argtypes = [POINTER(_TT), c_double, ctypes.c_int]
+        L.ttxo_tt_norm.argtypes = [POINTER(_TT), c_double]
+        L.ttxo_tt_norm.restype = c_double
+        L.ttxo_tt_dot.argtypes = [POINTER(_TT), POINTER(_TT)]
+        L.ttxo_tt_dot.restype = c_double
+        L.ttxo_tt_ijk.argtypes = [POINTER(_TT), POINTER(c_int32)]
+        L.ttxo_tt_ijk.restype = c_double
+        d = len(cores)
+        n = np.array([c.shape[1] for c in cores], dtype=np.int32)
+        r = np.array([cores[0].shape[0]] + [c.shape[2] for c in cores], dtype=np.int32)
+        self.p = L.ttxo_tt_new(d, _ip(n), _ip(r))
+        for k, c in enumerate(cores):
+            flat = np.asfortranarray(c, dtype=np.float64).ravel(order="F")
+            ctypes.memmove(self.p.contents.cores[k], flat.ctypes.data, flat.nbytes)
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            lib().ttxo_tt_free(self.p)
+            self.p = None
+
+    @property
+    def ranks(self):
+        d = self.p.contents.d
+        return np.array([self.p.contents.r[i] for i in range(d + 1)], dtype=np.int32)
+
+    def cores(self):
+        t, out = self.p.contents, []
+        for k in range(t.d):
+            shp = (t.r[k], t.n[k], t.r[k + 1])
+            out.append(np.ctypeslib.as_array(t.cores[k], shape=(shp[0] * shp[1] * shp[2],)).copy().reshape(shp, order="F"))
+        return out
+
+    def ort(self):
+        lib().ttxo_tt_ort(self.p)
+
+    def svd(self, tol, rmax=0):
+        lib().ttxo_tt_svd(self.p, tol, rmax)
+
+    def norm(self, tol=None):
+        return lib().ttxo_tt_norm(self.p, -1.0 if tol is None else tol)
+
+    def dot(self, other):
+        return lib().ttxo_tt_dot(self.p, other.p)
+
+    def ijk(self, ind):
+        a = np.ascontiguousarray(ind, dtype=np.int32)
+        return lib().ttxo_tt_ijk(self.p, _ip(a))
