@@ -114,6 +114,19 @@ int ttx_quad(ttx_engine *h, const double *w, double *val);
  * would need all cores).  pivot: d ints (worst sample) or NULL. */
 int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efro, double *ainf, double *afro, int32_t *pivot);
 
+/* tt_lib utilities on the tensor train resident on the device; single-process engines only.
+ * ttx_ort  : dtt_ort  (lib/tt.f90:130-198)  left-to-right Householder QR, in place
+ * ttx_svd  : dtt_svd  (lib/tt.f90:307-368)  rounding: ort, then truncated SVD right-to-left; tol relative
+ *            (lib/mat.f90:433-458 chop), rmax <= 0: absent
+ * ttx_norm : dtt_norm (lib/tt.f90:1074-1092) Frobenius norm, tol < 0: absent (the TT itself is left unchanged)
+ * ttx_dot  : dtt_dot  (lib/tt.f90:1155-1175) scalar product of two resident TTs with equal mode sizes
+ * ttx_ijk  : dtt_ijk  (lib/tt.f90:630-652)  one element, ind = d 1-based indices */
+int ttx_ort(ttx_engine *h);
+int ttx_svd(ttx_engine *h, double tol, int32_t rmax);
+int ttx_norm(ttx_engine *h, double tol, double *val);
+int ttx_dot(ttx_engine *hx, ttx_engine *hy, double *val);
+int ttx_ijk(ttx_engine *h, const int32_t *ind, double *val);
+
 /* profiling: with on != 0 the next ttx_run brackets every kernel launch with HIP events on the engine's
  * stream; ttx_kernel_stats then reports, per kernel kind, launches and total milliseconds. */
 #define TTX_K_LOTTERY 0

@@ -195,3 +195,68 @@ def test_accchk(m, n, r, piv, nlot, ng):
         assert list(g["pivot"]) == refpiv
         assert g["ainf"] == ref[2] and abs(g["afro"] - ref[3]) <= 1e-14 * ref[3]
         assert abs(g["einf"] - ref[0]) <= 1e-6 * ref[0] and abs(g["efro"] - ref[1]) <= 1e-6 * ref[1]
+
+
+def _full(cores):
+    """dense tensor of a small TT (numpy, test-side only)"""
+    t = cores[0]
+    for c in cores[1:]:
+        t = np.tensordot(t, c, axes=([t.ndim - 1], [0]))
+    return t.reshape(t.shape[1:-1])
+
+
+@pytest.mark.parametrize("m,n,r,piv,ng", [(6, 33, 12, 2, 1), (10, 25, 16, 2, 1), (7, 9, 8, 2, 3)])
+def test_tt_ort_svd_norm_dot(m, n, r, piv, ng):
+    """N1 (A12/A13): dtt_ort / dtt_svd / dtt_norm / dtt_dot / dtt_ijk on the device against the oracle's restatement
+    and the GENUINE reference's numbers (tests/golden/ttops_*.txt).  Floating point: LAPACK's QR/SVD are restated
+    (Householder with a different reduction order, Jacobi SVD, fp64 MFMA GEMMs): tolerance 1e-11 relative to the
+    norm; truncation ranks must be identical."""
+    import os
+    from golden_util import GOLDEN
+    from test_oracle_ttops import _fixture, probe_indices
+    s = D.ising_setup("c", m, n)
+    mk = lambda: E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], nproc=ng).run()
+    tt = mk()
+    cores0 = [tt.core(k) for k in range(1, tt.d + 1)]
+    ot = O.OracleTT(cores0)
+    nrm0 = ot.norm()
+    assert abs(tt.norm() - nrm0) <= 1e-12 * nrm0
+    assert np.array_equal(tt.ranks(), ot.ranks)                      # norm() leaves the TT untouched
+    assert all(np.array_equal(tt.core(k), cores0[k - 1]) for k in range(1, tt.d + 1))
+    assert abs(tt.dot(tt) - ot.dot(ot)) <= 1e-12 * nrm0 ** 2
+    ind = probe_indices(m, n, 2)
+    assert abs(tt.tijk(ind) - ot.ijk(ind)) <= 1e-13 * abs(ot.ijk(ind))
+    # ort: same tensor, orthonormal unfoldings (up to the reference's norm equalisation)
+    t1 = mk().ort()
+    o1 = O.OracleTT(cores0)
+    o1.ort()
+    assert np.array_equal(t1.ranks(), o1.ranks)
+    c1 = [t1.core(k) for k in range(1, t1.d + 1)]
+    scale = nrm0 ** (1.0 / t1.d)
+    for k in range(t1.d - 1):
+        u = c1[k].reshape(-1, c1[k].shape[2], order="F") / scale
+        assert np.allclose(u.T @ u, np.eye(u.shape[1]), atol=1e-12)
+    for k in range(1, 5):
+        ind = probe_indices(m, n, k)
+        assert abs(t1.tijk(ind) - ot.ijk(ind)) <= 1e-11 * nrm0 / np.sqrt(float(n) ** (m - 1)) + 1e-12 * abs(ot.ijk(ind))
+    if m <= 7:
+        assert np.allclose(_full(c1), _full(cores0), rtol=0, atol=1e-12 * np.abs(_full(cores0)).max())
+    # svd: identical truncation ranks, norms / dots / elements to tolerance
+    fx = None
+    f = os.path.join(GOLDEN, f"ttops_C_{m}_{n}_{r}_{piv}.txt")
+    if ng == 1 and os.path.exists(f):
+        fx = _fixture(os.path.basename(f))
+    for case, (tol, rmax) in enumerate([(1e-4, 0), (1e-8, 0), (1e-12, 5)], start=1):
+        t2 = mk().svd(tol, rmax)
+        o2 = O.OracleTT(cores0)
+        o2.svd(tol, rmax)
+        assert np.array_equal(t2.ranks(), o2.ranks), f"svd case {case}: ranks {t2.ranks()} vs {o2.ranks}"
+        assert abs(t2.norm() - o2.norm()) <= 1e-11 * nrm0
+        assert abs(tt.dot(t2) - ot.dot(o2)) <= 1e-11 * nrm0 ** 2
+        for k in range(1, 5):
+            ind = probe_indices(m, n, k)
+            assert abs(t2.tijk(ind) - o2.ijk(ind)) <= 1e-9 * abs(ot.ijk(ind))
+        if fx:
+            assert list(t2.ranks()) == [int(x) for x in fx["ranks_svd"][case - 1][1:]]
+            assert abs(t2.norm() - float(fx["norm_svd"][case - 1][1])) <= 1e-11 * nrm0
+            assert abs(tt.dot(t2) - float(fx["dot_svd"][case - 1][1])) <= 1e-11 * nrm0 ** 2

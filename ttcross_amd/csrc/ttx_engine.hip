@@ -21,6 +21,7 @@
 
 #include "../../include/ttx.h"
 #include "ttx_kernels.h"
+#include "ttx_ttops.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const char *fmt, ...)
@@ -100,6 +101,9 @@ struct ttx_engine {
     std::vector<hipEvent_t> evpool;
     int64_t k_launches[TTX_K_NKINDS] = {0};
     double k_ms[TTX_K_NKINDS] = {0}, k_bytes[TTX_K_NKINDS] = {0};
+    // tt_lib utilities: compact work buffers, allocated on first use
+    double *Wa = nullptr, *Wb = nullptr, *Wc = nullptr, *Wd = nullptr, *Sm = nullptr, *bak = nullptr;
+    int *Si = nullptr;
     size_t lds_half = 0, lds_lot = 0, lds_par = 0;
     int lot_batch = 1, half_vals = 0;
 };
@@ -778,6 +782,227 @@ extern "C" int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efr
         case TTX_FUN_STDNORM: return accchk_impl<FUN_STDNORM>(h, nlot, einf, efro, ainf, afro, pivot);
         default: return accchk_impl<FUN_MVN>(h, nlot, einf, efro, ainf, afro, pivot);
     }
+}
+
+// ---- tt_lib utilities (ort / svd / norm / dot) -------------------------------------------------------------
+static double *core_dev(const ttx_engine *h, int k)
+{
+    const int g = owner_of_core(h, k), first = h->own[h->g0 + g];
+    return h->P.arg + ((size_t)g * h->NC + (k - first)) * h->P.CS;
+}
+static int tt_prepare(ttx_engine *h, const char *who)
+{
+    if (!h || !h->ran) return fail(TTX_ESTATE, "%s: run dtt_dmrgg first", who);
+    if (h->W > 1) return fail(TTX_EINVAL, "%s: single-process engines only", who);
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    if (!h->Wa) {
+        const size_t CS = h->P.CS, RM = h->RM;
+        int rc;
+        if ((rc = dev_alloc(h, &h->Wa, CS)) || (rc = dev_alloc(h, &h->Wb, CS)) || (rc = dev_alloc(h, &h->Wc, CS)) || (rc = dev_alloc(h, &h->Wd, CS))) return rc;
+        if ((rc = dev_alloc(h, &h->Sm, 8 * RM * RM + 4 * RM + 16)) || (rc = dev_alloc(h, &h->Si, 2 * RM + 16))) return rc;
+    }
+    return TTX_OK;
+}
+static void push_ranks(ttx_engine *h)
+{
+    std::vector<int32_t> rr((size_t)h->G * (h->d + 2), 1);
+    for (int g = 0; g < h->G; g++) for (int p = 0; p <= h->d; p++) rr[(size_t)g * (h->d + 2) + p] = h->rfinal[p];
+    (void)hipMemcpyAsync(h->P.r, rr.data(), sizeof(int32_t) * rr.size(), hipMemcpyHostToDevice, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+}
+static inline dim3 g1(size_t n) { return dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)); }
+static int gemm(ttx_engine *h, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc)
+{
+    hipLaunchKernelGGL(k_gemm_mfma, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, h->stream, M, N, K, A, lda, B, ldb, C, ldc);
+    return TTX_OK;
+}
+static int qr(ttx_engine *h, int m, int n, double *A, double *R, double *tau)
+{
+    const size_t lds = sizeof(double) * ((size_t)m + n + 4);
+    if (lds > 150 * 1024) return fail(TTX_EINVAL, "dtt_ort: unfolding with %d rows does not fit the LDS-staged reflector", m);
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_qr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_qr, dim3(1), dim3(1024), lds, h->stream, m, n, A, R, tau);
+    return TTX_OK;
+}
+static int sumsq(ttx_engine *h, size_t n, const double *x, double *out_host)
+{
+    double *d = h->Sm + 8 * (size_t)h->RM * h->RM + 4 * h->RM;      // scratch scalar
+    hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(1024), 0, h->stream, n, x, d);
+    HIPCHECK(hipMemcpyAsync(out_host, d, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return TTX_OK;
+}
+
+static int ort_impl(ttx_engine *h)
+{
+    const int d = h->d, RM = h->RM; const size_t SS = h->P.SS;
+    std::vector<int32_t> &r = h->rfinal;
+    double *Rm = h->Sm, *tau = h->Sm + 8 * (size_t)RM * RM;
+    double lognrm = 0.0, s2; int rc;
+    for (int k = 1; k <= d - 1; k++) {                                  // lib/tt.f90:149-181
+        const int r0 = r[k - 1], n = h->n1[k], r1 = r[k], mm = r0 * n, nn = r1, mn = std::min(mm, nn), kk = h->n1[k + 1] * r[k + 1];
+        hipLaunchKernelGGL(k_pack_core, g1((size_t)mm * nn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, r0, n, r1, RM, SS, 0);
+        if ((rc = qr(h, mm, nn, h->Wa, Rm, tau))) return rc;
+        if ((rc = sumsq(h, (size_t)mn * nn, Rm, &s2))) return rc;
+        const double nrm = std::sqrt(s2);
+        if (nrm != 0.0) { hipLaunchKernelGGL(k_scal, g1((size_t)mn * nn), dim3(256), 0, h->stream, (size_t)mn * nn, Rm, 1.0 / nrm); lognrm += std::log(nrm); }
+        hipLaunchKernelGGL(k_unpack_core, g1((size_t)mm * mn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, r0, n, mn, RM, SS, 0, 1.0);
+        hipLaunchKernelGGL(k_pack_core, g1((size_t)nn * kk), dim3(256), 0, h->stream, core_dev(h, k + 1), h->Wb, nn, h->n1[k + 1], r[k + 1], RM, SS, 0);
+        gemm(h, mn, kk, nn, Rm, mn, h->Wb, nn, h->Wc, mn);             // R pushed into the next core (:175), fp64 MFMA
+        r[k] = mn;
+        hipLaunchKernelGGL(k_unpack_core, g1((size_t)mn * kk), dim3(256), 0, h->stream, core_dev(h, k + 1), h->Wc, mn, h->n1[k + 1], r[k + 1], RM, SS, 0, 1.0);
+    }
+    const size_t last = (size_t)r[d - 1] * h->n1[d] * r[d];
+    hipLaunchKernelGGL(k_pack_core, g1(last), dim3(256), 0, h->stream, core_dev(h, d), h->Wa, r[d - 1], h->n1[d], r[d], RM, SS, 0);
+    if ((rc = sumsq(h, last, h->Wa, &s2))) return rc;
+    double nl = std::sqrt(s2), lastscale = 1.0;
+    if (nl != 0.0) { lastscale = 1.0 / nl; lognrm += std::log(nl); }    // :184-188
+    lognrm /= d;
+    const double nrm = std::exp(lognrm);                                // :190-194
+    for (int k = 1; k <= d; k++)
+        hipLaunchKernelGGL(k_scal_core, g1((size_t)r[k - 1] * h->n1[k] * r[k]), dim3(256), 0, h->stream, core_dev(h, k), r[k - 1], h->n1[k], r[k], RM, SS,
+                           (k == d) ? nrm * lastscale : nrm);
+    push_ranks(h);
+    HIPCHECK(hipGetLastError());
+    return TTX_OK;
+}
+
+static int svd_impl(ttx_engine *h, double tol, int rmax)
+{
+    const int d = h->d, RM = h->RM; const size_t SS = h->P.SS;
+    if (d <= 1) return TTX_OK;
+    int rc = ort_impl(h);
+    if (rc) return rc;
+    std::vector<int32_t> &r = h->rfinal;
+    double *Rm = h->Sm, *Rt = Rm + (size_t)RM * RM, *Vb = Rt + (size_t)RM * RM, *US = Vb + (size_t)RM * RM, *Vs = US + (size_t)RM * RM;
+    double *tau = h->Sm + 8 * (size_t)RM * RM, *sv = tau + RM;
+    int *perm = h->Si, *info = h->Si + RM;
+    double lognrm = 0.0, s2;
+    std::vector<double> svh(RM);
+    for (int k = d; k >= 2; k--) {                                      // lib/tt.f90:329-356
+        const int mm = r[k - 1], n = h->n1[k], nn = n * r[k], kk = r[k - 2] * h->n1[k - 1];
+        if (mm > nn) return fail(TTX_EINVAL, "dtt_svd: core %d has more rows (%d) than columns (%d): not supported by the device path", k, mm, nn);
+        // A (mm x nn) = R1^T Q1^T with A^T = Q1 R1 ; R1^T = Ub S Vb^T  =>  A = Ub S (Q1 Vb)^T
+        hipLaunchKernelGGL(k_pack_core, g1((size_t)mm * nn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, mm, n, r[k], RM, SS, 1);
+        if ((rc = qr(h, nn, mm, h->Wa, Rm, tau))) return rc;            // Wa -> Q1 (nn x mm), Rm = R1 (mm x mm)
+        hipLaunchKernelGGL(k_transpose, g1((size_t)mm * mm), dim3(256), 0, h->stream, mm, mm, Rm, Rt);
+        hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(1024), 0, h->stream, mm, mm, Rt, Vb, sv, perm, info, 1, tol, rmax);
+        int inf[2];
+        HIPCHECK(hipMemcpyAsync(inf, info, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipMemcpyAsync(svh.data(), sv, sizeof(double) * mm, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        const int rr = inf[0];
+        s2 = 0.0; for (int j = 0; j < rr; j++) s2 += svh[j] * svh[j];
+        const double nrm = std::sqrt(s2);
+        if (nrm != 0.0) lognrm += std::log(nrm);
+        hipLaunchKernelGGL(k_take_cols, g1((size_t)mm * rr), dim3(256), 0, h->stream, mm, rr, Rt, mm, perm, sv, nrm != 0.0 ? 1.0 / nrm : 1.0, US);
+        hipLaunchKernelGGL(k_pack_core, g1((size_t)kk * mm), dim3(256), 0, h->stream, core_dev(h, k - 1), h->Wb, r[k - 2], h->n1[k - 1], mm, RM, SS, 0);
+        gemm(h, kk, rr, mm, h->Wb, kk, US, mm, h->Wc, kk);              // U S pushed into the previous core (:344)
+        hipLaunchKernelGGL(k_unpack_core, g1((size_t)kk * rr), dim3(256), 0, h->stream, core_dev(h, k - 1), h->Wc, r[k - 2], h->n1[k - 1], rr, RM, SS, 0, 1.0);
+        hipLaunchKernelGGL(k_take_cols, g1((size_t)mm * rr), dim3(256), 0, h->stream, mm, rr, Vb, mm, perm, (const double *)nullptr, 1.0, Vs);
+        gemm(h, nn, rr, mm, h->Wa, nn, Vs, mm, h->Wd, nn);              // Y = Q1 Vb(:, kept)  (nn x rr)
+        hipLaunchKernelGGL(k_unpack_core, g1((size_t)rr * nn), dim3(256), 0, h->stream, core_dev(h, k), h->Wd, rr, n, r[k], RM, SS, 1, 1.0);
+        r[k - 1] = rr;
+    }
+    const size_t first = (size_t)r[0] * h->n1[1] * r[1];
+    hipLaunchKernelGGL(k_pack_core, g1(first), dim3(256), 0, h->stream, core_dev(h, 1), h->Wa, r[0], h->n1[1], r[1], RM, SS, 0);
+    if ((rc = sumsq(h, first, h->Wa, &s2))) return rc;
+    double nf = std::sqrt(s2), firstscale = 1.0;
+    if (nf != 0.0) { firstscale = 1.0 / nf; lognrm += std::log(nf); }
+    lognrm /= d;
+    const double nrm = std::exp(lognrm);
+    for (int k = 1; k <= d; k++)
+        hipLaunchKernelGGL(k_scal_core, g1((size_t)r[k - 1] * h->n1[k] * r[k]), dim3(256), 0, h->stream, core_dev(h, k), r[k - 1], h->n1[k], r[k], RM, SS,
+                           (k == 1) ? nrm * firstscale : nrm);
+    push_ranks(h);
+    HIPCHECK(hipGetLastError());
+    return TTX_OK;
+}
+
+extern "C" int ttx_ort(ttx_engine *h) { int rc = tt_prepare(h, "dtt_ort"); return rc ? rc : ort_impl(h); }
+extern "C" int ttx_svd(ttx_engine *h, double tol, int32_t rmax) { int rc = tt_prepare(h, "dtt_svd"); return rc ? rc : svd_impl(h, tol, rmax); }
+
+extern "C" int ttx_norm(ttx_engine *h, double tol, double *val)
+{
+    int rc = tt_prepare(h, "dtt_norm");
+    if (rc) return rc;
+    if (!val) return fail(TTX_EINVAL, "dtt_norm: null result");
+    // the reference works on a copy (tmp = arg, lib/tt.f90:1082): back the cores and ranks up, restore afterwards
+    const size_t tot = (size_t)h->G * h->NC * h->P.CS;
+    if (!h->bak) { if ((rc = dev_alloc(h, &h->bak, tot))) return rc; }
+    HIPCHECK(hipMemcpyAsync(h->bak, h->P.arg, sizeof(double) * tot, hipMemcpyDeviceToDevice, h->stream));
+    std::vector<int32_t> rsave = h->rfinal;
+    const int d = h->d;
+    double s2 = 0.0;
+    if (tol >= 0.0) {
+        rc = svd_impl(h, tol, 0);
+        if (!rc) { const size_t sz = (size_t)h->rfinal[0] * h->n1[1] * h->rfinal[1];
+                   hipLaunchKernelGGL(k_pack_core, g1(sz), dim3(256), 0, h->stream, core_dev(h, 1), h->Wa, h->rfinal[0], h->n1[1], h->rfinal[1], h->RM, h->P.SS, 0);
+                   rc = sumsq(h, sz, h->Wa, &s2); }
+    } else {
+        rc = ort_impl(h);
+        if (!rc) { const size_t sz = (size_t)h->rfinal[d - 1] * h->n1[d] * h->rfinal[d];
+                   hipLaunchKernelGGL(k_pack_core, g1(sz), dim3(256), 0, h->stream, core_dev(h, d), h->Wa, h->rfinal[d - 1], h->n1[d], h->rfinal[d], h->RM, h->P.SS, 0);
+                   rc = sumsq(h, sz, h->Wa, &s2); }
+    }
+    HIPCHECK(hipMemcpyAsync(h->P.arg, h->bak, sizeof(double) * tot, hipMemcpyDeviceToDevice, h->stream));
+    h->rfinal = rsave;
+    push_ranks(h);
+    if (rc) return rc;
+    *val = std::pow(std::sqrt(s2), d);                                  // :1089
+    return TTX_OK;
+}
+
+extern "C" int ttx_dot(ttx_engine *x, ttx_engine *y, double *val)
+{
+    int rc = tt_prepare(x, "dtt_dot");
+    if (rc || (rc = tt_prepare(y, "dtt_dot"))) return rc;
+    if (!val) return fail(TTX_EINVAL, "dtt_dot: null result");
+    if (x->d != y->d) return fail(TTX_EINVAL, "dtt_dot: dimensions not match");          // lib/tt.f90:1162
+    for (int k = 1; k <= x->d; k++) if (x->n1[k] != y->n1[k]) return fail(TTX_EINVAL, "dtt_dot: sizes not match");
+    if (x->cfg.device != y->cfg.device) return fail(TTX_EINVAL, "dtt_dot: both tensor trains must live on the same GPU");
+    const int d = x->d;
+    double *phi = x->Sm, *phi2 = x->Sm + (size_t)x->RM * x->RM;        // needs rx*ry <= RM_x^2: checked below
+    const double one = 1.0;
+    HIPCHECK(hipMemcpyAsync(phi, &one, sizeof(double), hipMemcpyHostToDevice, x->stream));
+    HIPCHECK(hipStreamSynchronize(y->stream));
+    for (int i = 1; i <= d; i++) {
+        const int rx0 = x->rfinal[i - 1], rx1 = x->rfinal[i], ry0 = y->rfinal[i - 1], ry1 = y->rfinal[i], n = x->n1[i];
+        if ((size_t)rx1 * ry1 > (size_t)x->RM * x->RM || (size_t)rx0 * n * ry1 > x->P.CS) return fail(TTX_EINVAL, "dtt_dot: ranks of y exceed the work space of x");
+        hipLaunchKernelGGL(k_pack_core, g1((size_t)ry0 * n * ry1), dim3(256), 0, x->stream, core_dev(y, i), x->Wb, ry0, n, ry1, y->RM, y->P.SS, 0);
+        gemm(x, rx0, n * ry1, ry0, phi, rx0, x->Wb, ry0, x->Wc, rx0);                       // :1169
+        hipLaunchKernelGGL(k_pack_core, g1((size_t)rx0 * n * rx1), dim3(256), 0, x->stream, core_dev(x, i), x->Wa, rx0, n, rx1, x->RM, x->P.SS, 0);
+        hipLaunchKernelGGL(k_transpose, g1((size_t)rx0 * n * rx1), dim3(256), 0, x->stream, rx0 * n, rx1, x->Wa, x->Wd);
+        gemm(x, rx1, ry1, rx0 * n, x->Wd, rx1, x->Wc, rx0 * n, phi2, rx1);                  // :1170
+        std::swap(phi, phi2);
+    }
+    HIPCHECK(hipMemcpyAsync(val, phi, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIPCHECK(hipStreamSynchronize(x->stream));
+    HIPCHECK(hipGetLastError());
+    return TTX_OK;
+}
+
+extern "C" int ttx_ijk(ttx_engine *h, const int32_t *ind, double *val)
+{
+    int rc = tt_prepare(h, "dtt_ijk");
+    if (rc) return rc;
+    if (!ind || !val) return fail(TTX_EINVAL, "dtt_ijk: null argument");
+    const int d = h->d;
+    for (int k = 1; k <= d; k++) if (ind[k - 1] <= 0 || ind[k - 1] > h->n1[k]) { *val = -3.0; return TTX_OK; }   // lib/tt.f90:639
+    // x = U_d(:, ind_d, 1); for i = d-1..1: x = U_i(:, ind_i, :) x -- matrix-vector steps through the GEMM kernel
+    double *xv = h->Sm, *zv = h->Sm + h->RM;
+    hipLaunchKernelGGL(k_pack_core, g1((size_t)h->rfinal[d - 1] * h->n1[d] * h->rfinal[d]), dim3(256), 0, h->stream, core_dev(h, d), h->Wa, h->rfinal[d - 1], h->n1[d], h->rfinal[d], h->RM, h->P.SS, 0);
+    HIPCHECK(hipMemcpyAsync(xv, h->Wa + (size_t)h->rfinal[d - 1] * (ind[d - 1] - 1), sizeof(double) * h->rfinal[d - 1], hipMemcpyDeviceToDevice, h->stream));
+    for (int i = d - 1; i >= 1; i--) {
+        const int q0 = h->rfinal[i - 1], q1 = h->rfinal[i], n = h->n1[i];
+        hipLaunchKernelGGL(k_pack_core, g1((size_t)q0 * n * q1), dim3(256), 0, h->stream, core_dev(h, i), h->Wa, q0, n, q1, h->RM, h->P.SS, 0);
+        gemm(h, q0, 1, q1, h->Wa + (size_t)q0 * (ind[i - 1] - 1), q0 * n, xv, q1, zv, q0);
+        std::swap(xv, zv);
+    }
+    HIPCHECK(hipMemcpyAsync(val, xv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipGetLastError());
+    return TTX_OK;
 }
 
 extern "C" int ttx_set_profile(ttx_engine *h, int on) { if (!h) return fail(TTX_EINVAL, "null"); h->profile = on != 0; return TTX_OK; }

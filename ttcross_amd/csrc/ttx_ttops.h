@@ -1,0 +1,266 @@
+// ttx_ttops.h -- device kernels of the tt_lib utilities on the resident tensor train:
+//   dtt_ort  (lib/tt.f90:130-198): left-to-right Householder QR of the tall-skinny (r0*n) x r1 unfoldings,
+//            R pushed into the next core by an fp64-MFMA GEMM
+//   dtt_svd  (lib/tt.f90:307-368): right-to-left truncated SVD of the r0 x (n*r1) unfoldings
+//   dtt_norm (:1074-1092), dtt_dot (:1155-1175)
+// All kernels work on COMPACT column-major work buffers (pack/unpack from the padded core layout of ttx_dev.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ttx_dev.h"
+
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+// padded core (i + RM*j + SS*s) -> compact (i + r0*(j + n*s)); tr: write the transpose of the r0 x (n*r1) unfolding
+__global__ void k_pack_core(const double *core, double *w, int r0, int n, int r1, int RM, size_t SS, int tr)
+{
+    const size_t tot = (size_t)r0 * n * r1;
+    for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < tot; x += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(x % r0); size_t c = x / r0; int j = (int)(c % n), s = (int)(c / n);
+        double v = core[i + (size_t)RM * j + SS * s];
+        if (tr) w[c + (size_t)n * r1 * i] = v; else w[x] = v;
+    }
+}
+__global__ void k_unpack_core(double *core, const double *w, int r0, int n, int r1, int RM, size_t SS, int tr, double scale)
+{
+    const size_t tot = (size_t)r0 * n * r1;
+    for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < tot; x += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(x % r0); size_t c = x / r0; int j = (int)(c % n), s = (int)(c / n);
+        double v = tr ? w[c + (size_t)n * r1 * i] : w[x];
+        core[i + (size_t)RM * j + SS * s] = scale * v;
+    }
+}
+
+__device__ __forceinline__ double tt_block_sum(double v, double *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int x = 0; x < nw; x++) r += sh[x];
+    return r;
+}
+
+// Householder QR of A (m x n, compact, in place), LAPACK dgeqr2 / dlarfg / dlarf then dorg2r, one 1024-thread
+// workgroup: the reflector lives in LDS, the n-wide panel of w = A^T v in LDS; Rout (mn x n) gets the upper
+// trapezoid (zeros below the diagonal); on exit A holds the first mn columns of Q.
+__global__ __launch_bounds__(1024) void k_qr(int m, int n, double *A, double *Rout, double *tau_out)
+{
+    extern __shared__ __align__(16) double sm[];
+    double *vsh = sm;                 // m
+    double *wsh = sm + m;             // n
+    __shared__ double red[16];
+    __shared__ double s_tau, s_beta, s_scale;
+    const int tid = threadIdx.x, nt = blockDim.x, mn = m < n ? m : n;
+    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    for (int i = 0; i < mn; i++) {
+        double *x = A + i + (size_t)m * i;
+        const int len = m - i;
+        double p = 0.0;
+        for (int r = 1 + tid; r < len; r += nt) p += x[r] * x[r];
+        const double xn2 = tt_block_sum(p, red);
+        if (tid == 0) {
+            const double alpha = x[0], xn = sqrt(xn2);
+            if (xn == 0.0) { s_tau = 0.0; s_beta = alpha; s_scale = 0.0; }
+            else {
+                const double beta = -copysign(hypot(alpha, xn), alpha);
+                s_tau = (beta - alpha) / beta; s_beta = beta; s_scale = 1.0 / (alpha - beta);
+            }
+            tau_out[i] = s_tau;
+        }
+        __syncthreads();
+        for (int r = tid; r < len; r += nt) { double v = (r == 0) ? 1.0 : x[r] * s_scale; vsh[r] = v; if (r > 0) x[r] = v; }
+        __syncthreads();
+        if (tid == 0) x[0] = s_beta;
+        // w_c = v^T A(i:, c) for c > i : one wave per column
+        for (int c = i + 1 + wv; c < n; c += nw) {
+            const double *cc = A + i + (size_t)m * c;
+            double q = 0.0;
+            for (int r = lane; r < len; r += 64) q += vsh[r] * cc[r];
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            if (lane == 0) wsh[c] = q * s_tau;
+        }
+        __syncthreads();
+        for (int c = i + 1 + wv; c < n; c += nw) {
+            double *cc = A + i + (size_t)m * c;
+            const double wc = wsh[c];
+            for (int r = lane; r < len; r += 64) cc[r] -= vsh[r] * wc;
+        }
+        __syncthreads();
+    }
+    // R
+    for (int x = tid; x < mn * n; x += nt) { int r = x % mn, c = x / mn; Rout[x] = (r <= c) ? A[r + (size_t)m * c] : 0.0; }
+    __syncthreads();
+    // dorg2r
+    for (int i = mn - 1; i >= 0; i--) {
+        double *x = A + i + (size_t)m * i;
+        const int len = m - i;
+        const double tau = tau_out[i];
+        for (int r = tid; r < len; r += nt) vsh[r] = (r == 0) ? 1.0 : x[r];
+        __syncthreads();
+        for (int c = i + 1 + wv; c < mn; c += nw) {
+            const double *cc = A + i + (size_t)m * c;
+            double q = 0.0;
+            for (int r = lane; r < len; r += 64) q += vsh[r] * cc[r];
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            if (lane == 0) wsh[c] = q * tau;
+        }
+        __syncthreads();
+        for (int c = i + 1 + wv; c < mn; c += nw) {
+            double *cc = A + i + (size_t)m * c;
+            const double wc = wsh[c];
+            for (int r = lane; r < len; r += 64) cc[r] -= vsh[r] * wc;
+        }
+        for (int r = tid; r < len; r += nt) x[r] = (r == 0) ? 1.0 - tau : -tau * vsh[r];
+        for (int r = tid; r < i; r += nt) A[r + (size_t)m * i] = 0.0;
+        __syncthreads();
+    }
+}
+
+// C (M x N, ldc) = A (M x K, lda) * B (K x N, ldb), fp64 on the matrix cores: one wave per 16x16 tile of C,
+// v_mfma_f64_16x16x4_f64 per k-step of 4.  Operand lane maps (cdna_hip_programming.md sec. 3): A[row l&15][k l>>4],
+// B[k l>>4][col l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
+__global__ __launch_bounds__(256) void k_gemm_mfma(int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc)
+{
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int tm = blockIdx.y * 16, tn = (blockIdx.x * 4 + wave) * 16;
+    if (tn >= N) return;
+    const int ar = tm + (l & 15), bc = tn + (l & 15), kq = l >> 4;
+    dbl4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kq;
+        const double a = (ar < M && k < K) ? A[ar + (size_t)lda * k] : 0.0;
+        const double b = (bc < N && k < K) ? B[k + (size_t)ldb * bc] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int row = tm + (l >> 4) + 4 * reg, col = tn + (l & 15);
+        if (row < M && col < N) C[row + (size_t)ldc * col] = acc[reg];
+    }
+}
+
+// ||x||_2^2 of n doubles -> out[0] (single block)
+__global__ __launch_bounds__(1024) void k_sumsq(size_t n, const double *x, double *out)
+{
+    __shared__ double red[16];
+    double p = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) p += x[i] * x[i];
+    p = tt_block_sum(p, red);
+    if (threadIdx.x == 0) out[0] = p;
+}
+__global__ void k_scal(size_t n, double *x, double a)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= a;
+}
+// scale every element of a padded core
+__global__ void k_scal_core(double *core, int r0, int n, int r1, int RM, size_t SS, double a)
+{
+    const size_t tot = (size_t)r0 * n * r1;
+    for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < tot; x += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(x % r0); size_t c = x / r0; int j = (int)(c % n), s = (int)(c / n);
+        core[i + (size_t)RM * j + SS * s] *= a;
+    }
+}
+
+// One-sided Jacobi (Hestenes) SVD of X (p x q, p >= q, compact, in place -> U), V (q x q) accumulated, s[q]; then
+// ordering (perm[j] = column holding the j-th largest singular value) and the reference's chop (lib/mat.f90:433-458)
+// info[0] = kept rank rr, info[1] = sweeps; sout[q] sorted singular values; one 1024-thread workgroup, the
+// q/2 disjoint column pairs of a round-robin round rotate concurrently.
+__global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *X, double *V, double *sout, int *perm, int *info,
+                                                     int has_tol, double tol, int rmax)
+{
+    __shared__ int s_rot;
+    __shared__ double ssh[256];
+    __shared__ int psh[256];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int x = tid; x < q * q; x += nt) V[x] = ((x % q) == (x / q)) ? 1.0 : 0.0;
+    __syncthreads();
+    const int qq = (q + 1) & ~1;                 // players of the tournament (one dummy if q is odd)
+    const int npair = qq / 2;
+    int tpp = nt / npair; if (tpp > 64) tpp = 64; if (tpp < 1) tpp = 1;
+    // threads per pair: a power of two <= 64 so that a pair never straddles a wave
+    int t2 = 1; while (t2 * 2 <= tpp) t2 *= 2; tpp = t2;
+    const int pairs_per_pass = nt / tpp;
+    int sweeps = 0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < qq - 1; round++) {
+            for (int p0 = 0; p0 < npair; p0 += pairs_per_pass) {
+                const int pi = p0 + tid / tpp, sub = tid % tpp;
+                if (pi < npair) {
+                    int a = (pi == 0) ? qq - 1 : (round + pi) % (qq - 1);
+                    int b = (round - pi + (qq - 1)) % (qq - 1);
+                    if (a > b) { int t = a; a = b; b = t; }
+                    if (b < q) {
+                        double *xa = X + (size_t)p * a, *xb = X + (size_t)p * b;
+                        double al = 0.0, be = 0.0, ga = 0.0;
+                        for (int i = sub; i < p; i += tpp) { double u = xa[i], w = xb[i]; al += u * u; be += w * w; ga += u * w; }
+                        for (int o = tpp >> 1; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
+                        if (!(fabs(ga) <= 1e-16 * sqrt(al * be) || ga == 0.0)) {
+                            if (sub == 0) atomicAdd(&s_rot, 1);
+                            const double zeta = (be - al) / (2.0 * ga);
+                            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                            const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                            for (int i = sub; i < p; i += tpp) { double u = xa[i], w = xb[i]; xa[i] = c * u - sn * w; xb[i] = sn * u + c * w; }
+                            double *va = V + (size_t)q * a, *vb = V + (size_t)q * b;
+                            for (int i = sub; i < q; i += tpp) { double u = va[i], w = vb[i]; va[i] = c * u - sn * w; vb[i] = sn * u + c * w; }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        sweeps = sweep + 1;
+        if (s_rot == 0) break;
+        __syncthreads();
+    }
+    // singular values and normalised columns
+    for (int j = tid / 64; j < q; j += nt / 64) {
+        double *xj = X + (size_t)p * j; double s2 = 0.0;
+        for (int i = tid & 63; i < p; i += 64) s2 += xj[i] * xj[i];
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        const double s = sqrt(s2);
+        if ((tid & 63) == 0) ssh[j] = s;
+        if (s > 0.0) for (int i = tid & 63; i < p; i += 64) xj[i] /= s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int j = 0; j < q; j++) psh[j] = j;
+        for (int j = 0; j < q - 1; j++) {               // selection sort, descending
+            int mx = j;
+            for (int k = j + 1; k < q; k++) if (ssh[psh[k]] > ssh[psh[mx]]) mx = k;
+            int t = psh[j]; psh[j] = psh[mx]; psh[mx] = t;
+        }
+        for (int j = 0; j < q; j++) { perm[j] = psh[j]; sout[j] = ssh[psh[j]]; }
+        // chop (lib/mat.f90:433-458)
+        int r = q; double er2 = 0.0;
+        if (rmax > 0 && rmax < r) { for (int i = rmax; i < r; i++) er2 += sout[i] * sout[i]; r = rmax; }
+        if (has_tol) {
+            double nrm = 0.0; for (int i = 0; i < q; i++) nrm += sout[i] * sout[i];
+            const double bound = tol * tol * nrm;
+            double er = er2 + sout[r - 1] * sout[r - 1];
+            while (er < bound) { er2 = er; r--; er = er + sout[r - 1] * sout[r - 1]; }
+        }
+        info[0] = r; info[1] = sweeps;
+    }
+}
+
+// out (rows x rr) <- in(:, perm[0..rr)) * diag(scale[c])   (scale == nullptr: 1)
+__global__ void k_take_cols(int rows, int rr, const double *in, int ldin, const int *perm, const double *scale, double sdiv, double *out)
+{
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < rows * rr; x += gridDim.x * blockDim.x) {
+        int i = x % rows, c = x / rows;
+        out[x] = in[i + (size_t)ldin * perm[c]] * (scale ? scale[c] * sdiv : 1.0);
+    }
+}
+// out (rr x cols) <- transpose of in (cols x rr)
+__global__ void k_transpose(int rows, int cols, const double *in, double *out)
+{
+    for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < (size_t)rows * cols; x += (size_t)gridDim.x * blockDim.x) {
+        size_t i = x % rows, c = x / rows;
+        out[c + (size_t)cols * i] = in[x];
+    }
+}

@@ -82,6 +82,11 @@ def load_library():
     L.ttx_get_core.argtypes = [c_void_p, ctypes.c_int, POINTER(c_double)]
     L.ttx_quad.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
     L.ttx_set_profile.argtypes = [c_void_p, ctypes.c_int]
+    L.ttx_ort.argtypes = [c_void_p]
+    L.ttx_svd.argtypes = [c_void_p, c_double, c_int32]
+    L.ttx_norm.argtypes = [c_void_p, c_double, POINTER(c_double)]
+    L.ttx_dot.argtypes = [c_void_p, c_void_p, POINTER(c_double)]
+    L.ttx_ijk.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_double)]
     L.ttx_accchk.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int32)]
     L.ttx_kernel_stats.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
     L.ttx_k_residual_argmax.argtypes = [c_int32, c_int32, c_int32, POINTER(c_double), POINTER(c_double),
@@ -272,6 +277,31 @@ class TTCross:
         v = c_double()
         wa = None if w is None else np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.float64).ravel() for q in w]))
         _check(load_library().ttx_quad(self._h, _dp(wa), ctypes.byref(v)))
+        return v.value
+
+    # ---- tt_lib utilities on the resident TT (lib/tt.f90: ort, svd, norm, dot_product, tijk) --------------
+    def ort(self):
+        _check(load_library().ttx_ort(self._h))
+        return self
+
+    def svd(self, tol, rmax=0):
+        _check(load_library().ttx_svd(self._h, float(tol), int(rmax)))
+        return self
+
+    def norm(self, tol=None):
+        v = c_double()
+        _check(load_library().ttx_norm(self._h, -1.0 if tol is None else float(tol), ctypes.byref(v)))
+        return v.value
+
+    def dot(self, other):
+        v = c_double()
+        _check(load_library().ttx_dot(self._h, other._h, ctypes.byref(v)))
+        return v.value
+
+    def tijk(self, ind):
+        a = np.ascontiguousarray(ind, dtype=np.int32)
+        v = c_double()
+        _check(load_library().ttx_ijk(self._h, _ip(a), ctypes.byref(v)))
         return v.value
 
     def accchk(self, nlot):
