@@ -28,6 +28,12 @@ module tt_lib
  interface dealloc; module procedure dtt_dealloc; end interface
  interface ones;    module procedure dtt_ones;    end interface
  interface erank;   module procedure dtt_rank;    end interface
+ ! utilities that run on the tensor train resident on the device after dtt_dmrgg (lib/tt.f90:54-124 generics)
+ interface ort;         module procedure dtt_ort;  end interface
+ interface svd;         module procedure dtt_svd;  end interface
+ interface norm;        module procedure dtt_norm; end interface
+ interface dot_product; module procedure dtt_dot;  end interface
+ interface tijk;        module procedure dtt_ijk;  end interface
 contains
  subroutine dtt_alloc(arg)
   type(dtt),intent(inout) :: arg
@@ -58,6 +64,57 @@ contains
   call dtt_alloc(arg)
   do k=arg%l,arg%m; arg%u(k)%p=1.d0; end do
  end subroutine
+ subroutine dtt_pull(arg)
+  ! refresh arg%r and arg%u from the device-resident tensor train
+  use ttx_c
+  type(dtt),intent(inout) :: arg
+  integer(c_int32_t) :: rk(0:tt_size)
+  integer :: k
+  call ttx_check(ttx_get_ranks(arg%ttx,rk),'tt_lib')
+  arg%r(0:arg%m)=rk(0:arg%m)
+  call dtt_alloc(arg)
+  do k=1,arg%m; call ttx_check(ttx_get_core(arg%ttx,int(k,c_int),arg%u(k)%p),'tt_lib'); end do
+ end subroutine
+ subroutine dtt_resident(arg,who)
+  type(dtt),intent(in) :: arg
+  character(len=*),intent(in) :: who
+  if(.not.c_associated(arg%ttx))then;write(*,*)who,': tensor train is not resident on the device (call dtt_dmrgg first)';stop;endif
+ end subroutine
+ subroutine dtt_ort(arg)
+  use ttx_c
+  type(dtt),intent(inout),target :: arg
+  call dtt_resident(arg,'dtt_ort'); call ttx_check(ttx_ort(arg%ttx),'dtt_ort'); call dtt_pull(arg)
+ end subroutine
+ subroutine dtt_svd(arg,tol,rmax)
+  use ttx_c
+  type(dtt),intent(inout),target :: arg
+  double precision,intent(in) :: tol
+  integer,intent(in),optional :: rmax
+  integer(c_int32_t) :: rm
+  rm=0; if(present(rmax))rm=rmax
+  call dtt_resident(arg,'dtt_svd'); call ttx_check(ttx_svd(arg%ttx,tol,rm),'dtt_svd'); call dtt_pull(arg)
+ end subroutine
+ double precision function dtt_norm(arg,tol) result(nrm)
+  use ttx_c
+  type(dtt),intent(in) :: arg
+  double precision,intent(in),optional :: tol
+  real(c_double) :: t
+  t=-1.d0; if(present(tol))t=tol
+  call dtt_resident(arg,'dtt_norm'); call ttx_check(ttx_norm(arg%ttx,t,nrm),'dtt_norm')
+ end function
+ double precision function dtt_dot(x,y) result(dot)
+  use ttx_c
+  type(dtt),intent(in) :: x,y
+  call dtt_resident(x,'dtt_dot'); call dtt_resident(y,'dtt_dot'); call ttx_check(ttx_dot(x%ttx,y%ttx,dot),'dtt_dot')
+ end function
+ double precision function dtt_ijk(arg,ind) result(a)
+  use ttx_c
+  type(dtt),intent(in) :: arg
+  integer,intent(in) :: ind(:)
+  integer(c_int32_t) :: ix(arg%m)
+  ix=ind(1:arg%m)
+  call dtt_resident(arg,'dtt_ijk'); call ttx_check(ttx_ijk(arg%ttx,ix,a),'dtt_ijk')
+ end function
  double precision function dtt_rank(arg) result(r)
   type(dtt),intent(in) :: arg
   integer :: l,m,i,a,b,d

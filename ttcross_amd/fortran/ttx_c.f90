@@ -54,7 +54,22 @@ module ttx_c
   function ttx_quad(h,w,val) bind(C,name='ttx_quad') result(rc)
    import; type(c_ptr),value :: h; type(c_ptr),value :: w; real(c_double),intent(out) :: val; integer(c_int) :: rc
   end function
- function ttx_accchk(h,nlot,einf,efro,ainf,afro,pivot) bind(C,name='ttx_accchk') result(rc)
+  function ttx_ort(h) bind(C,name='ttx_ort') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int) :: rc
+  end function
+  function ttx_svd(h,tol,rmax) bind(C,name='ttx_svd') result(rc)
+   import; type(c_ptr),value :: h; real(c_double),value :: tol; integer(c_int32_t),value :: rmax; integer(c_int) :: rc
+  end function
+  function ttx_norm(h,tol,val) bind(C,name='ttx_norm') result(rc)
+   import; type(c_ptr),value :: h; real(c_double),value :: tol; real(c_double),intent(out) :: val; integer(c_int) :: rc
+  end function
+  function ttx_dot(hx,hy,val) bind(C,name='ttx_dot') result(rc)
+   import; type(c_ptr),value :: hx,hy; real(c_double),intent(out) :: val; integer(c_int) :: rc
+  end function
+  function ttx_ijk(h,ind,val) bind(C,name='ttx_ijk') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int32_t),intent(in) :: ind(*); real(c_double),intent(out) :: val; integer(c_int) :: rc
+  end function
+  function ttx_accchk(h,nlot,einf,efro,ainf,afro,pivot) bind(C,name='ttx_accchk') result(rc)
    import; type(c_ptr),value :: h; integer(c_int32_t),value :: nlot; real(c_double),intent(out) :: einf,efro,ainf,afro
    integer(c_int32_t),intent(out) :: pivot(*); integer(c_int) :: rc
   end function
