@@ -126,6 +126,10 @@ int ttx_svd(ttx_engine *h, double tol, int32_t rmax);
 int ttx_norm(ttx_engine *h, double tol, double *val);
 int ttx_dot(ttx_engine *hx, ttx_engine *hy, double *val);
 int ttx_ijk(ttx_engine *h, const int32_t *ind, double *val);
+/* ztt_quad (lib/dmrgg.f90:1418-1523) of the (real) resident TT with COMPLEX rank-1 weights, batched over nf weight
+ * sets (the 32 frequencies of test_crs_chf.f90:153-168 in one call): w = nf blocks of sum(n) interleaved (re, im)
+ * doubles, out = nf (re, im) pairs.  Single-process engines only. */
+int ttx_zquad(ttx_engine *h, int32_t nf, const double *w, double *out);
 
 /* profiling: with on != 0 the next ttx_run brackets every kernel launch with HIP events on the engine's
  * stream; ttx_kernel_stats then reports, per kernel kind, launches and total milliseconds. */

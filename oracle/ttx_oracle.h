@@ -91,6 +91,7 @@ void ttxo_tt_svd(ttxo_tt *t, double tol, int rmax);
 double ttxo_tt_norm(const ttxo_tt *t, double tol);
 double ttxo_tt_dot(const ttxo_tt *x, const ttxo_tt *y);
 double ttxo_tt_ijk(const ttxo_tt *t, const int32_t *ind);
+void ttxo_tt_zquad(const ttxo_tt *t, const double *w /* interleaved re,im */, double *out /* re, im */);   /* lib/dmrgg.f90:1418 */
 ttxo_tt *ttxo_tt_new(int d, const int32_t *n, const int32_t *r);
 void ttxo_tt_free(ttxo_tt *b);
 /* lib/quad.f90:97-131 */

@@ -262,3 +262,33 @@ ttxo_tt *ttxo_tt_new(int d, const int32_t *n, const int32_t *r)
     return b;
 }
 void ttxo_tt_free(ttxo_tt *b) { if (b) tt_free(b); }
+
+/* lib/dmrgg.f90:1418-1523 ztt_quad of a REAL tensor train with complex rank-1 weights (nproc = 1): per core
+ * curr(:,k) = sum_j U(:,j,k) w_j (zgemv), running product prev*curr (zgemm), both in netlib order.
+ * w: d blocks of n[k] complex weights, interleaved (re, im); out[0] = re, out[1] = im */
+#include <complex.h>
+void ttxo_tt_zquad(const ttxo_tt *t, const double *w, double *out)
+{
+    const int d = t->d;
+    double complex *prev = NULL;
+    int rf = t->r[0];
+    size_t off = 0;
+    for (int p = 0; p < d; p++) {
+        int r0 = t->r[p], r1 = t->r[p + 1], n = t->n[p];
+        double complex *curr = (double complex *)calloc((size_t)r0 * r1 + 1, sizeof(double complex));
+        for (int k = 0; k < r1; k++)
+            for (int j = 0; j < n; j++) {
+                double complex temp = w[2 * (off + j)] + I * w[2 * (off + j) + 1];
+                for (int i = 0; i < r0; i++) curr[i + (size_t)r0 * k] += temp * t->cores[p][i + (size_t)r0 * (j + (size_t)n * k)];
+            }
+        off += n;
+        if (!prev) prev = curr;
+        else {
+            double complex *next = (double complex *)calloc((size_t)rf * r1 + 1, sizeof(double complex));
+            for (int c = 0; c < r1; c++) for (int l = 0; l < r0; l++) { double complex temp = curr[l + (size_t)r0 * c]; for (int i = 0; i < rf; i++) next[i + (size_t)rf * c] += temp * prev[i + (size_t)rf * l]; }
+            free(prev); free(curr); prev = next;
+        }
+    }
+    out[0] = creal(prev[0]); out[1] = cimag(prev[0]);
+    free(prev);
+}

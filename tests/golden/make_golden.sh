@@ -50,3 +50,8 @@ amdflang -O2 -fopenmp -I/opt/conda/include -Ioracle/_ref/mod tests/golden/ref_tt
 oracle/_ref/ref_ttops 6 33 12 2 | grep -vE "n_evals" > $G/ttops_C_6_33_12_2.txt
 oracle/_ref/ref_ttops 10 25 16 2 | grep -vE "n_evals" > $G/ttops_C_10_25_16_2.txt
 rm -f *.mod
+# ztt_quad (complex-weight quadrature) of the genuine reference
+amdflang -O2 -fopenmp -I/opt/conda/include -Ioracle/_ref/mod tests/golden/ref_zquad.f90 oracle/_ref/obj/{zero,nan,trans,default,timef,say,rnd,ptype,ort,lr,mat,quad,tt,dmrgg,mvn_pdf}.o \
+  -o oracle/_ref/ref_zquad -L/opt/conda/lib -lmpifort -lmpi -lmkl_rt -Wl,-rpath,/opt/conda/lib -Wl,-rpath,/opt/rocm/lib/llvm/lib 2>/dev/null
+oracle/_ref/ref_zquad 6 33 12 2 | grep zquad > $G/zquad_C_6_33_12_2.txt
+rm -f *.mod

@@ -189,6 +189,15 @@ class OracleTT:
     def dot(self, other):
         return lib().ttxo_tt_dot(self.p, other.p)
 
+    def zquad(self, w):
+        """w: complex array of length sum(n) (rank-1 weights per mode, concatenated)"""
+        L = lib()
+        L.ttxo_tt_zquad.argtypes = [POINTER(_TT), POINTER(c_double), POINTER(c_double)]
+        ww = np.ascontiguousarray(np.asarray(w, dtype=np.complex128)).view(np.float64)
+        out = np.zeros(2)
+        L.ttxo_tt_zquad(self.p, _dp(ww), _dp(out))
+        return complex(out[0], out[1])
+
     def ijk(self, ind):
         a = np.ascontiguousarray(ind, dtype=np.int32)
         return lib().ttxo_tt_ijk(self.p, _ip(a))

@@ -260,3 +260,25 @@ def test_tt_ort_svd_norm_dot(m, n, r, piv, ng):
             assert list(t2.ranks()) == [int(x) for x in fx["ranks_svd"][case - 1][1:]]
             assert abs(t2.norm() - float(fx["norm_svd"][case - 1][1])) <= 1e-11 * nrm0
             assert abs(tt.dot(t2) - float(fx["dot_svd"][case - 1][1])) <= 1e-11 * nrm0 ** 2
+
+
+def test_zquad_complex_weights():
+    """N2 (A15): ztt_quad with the complex weights of the characteristic-function driver, batched over frequencies,
+    against the oracle (tolerance 1e-13 of |value|) and the GENUINE reference (tests/golden/zquad_*.txt)."""
+    import os
+    from golden_util import GOLDEN
+    m, n, r, piv = 6, 33, 12, 2
+    s = D.ising_setup("c", m, n)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"]).run()
+    ot = O.OracleTT([tt.core(k) for k in range(1, tt.d + 1)])
+    sc = float(n // 2)
+    x = s["par"][:n]
+    W = np.array([np.tile((1.0 / sc) * np.exp(1j * (k * np.pi / 300.0) * np.exp(x) / (m - 1)), m - 1) for k in range(8)])
+    got = tt.zquad(W)
+    for k in range(8):
+        want = ot.zquad(W[k])
+        assert abs(got[k] - want) <= 1e-13 * abs(want)
+    ref = [l.split() for l in open(os.path.join(GOLDEN, "zquad_C_6_33_12_2.txt"))]
+    for k in range(8):
+        want = complex(float(ref[k][2]), float(ref[k][3]))
+        assert abs(got[k] - want) <= 1e-12 * abs(want)

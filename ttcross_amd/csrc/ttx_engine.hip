@@ -982,6 +982,34 @@ extern "C" int ttx_dot(ttx_engine *x, ttx_engine *y, double *val)
     return TTX_OK;
 }
 
+extern "C" int ttx_zquad(ttx_engine *h, int32_t nf, const double *w, double *out)
+{
+    int rc = tt_prepare(h, "ztt_quad");
+    if (rc) return rc;
+    if (nf < 1 || !w || !out) return fail(TTX_EINVAL, "ztt_quad: bad argument");
+    const int d = h->d, RM = h->RM;
+    size_t sumn = 0;
+    for (int k = 1; k <= d; k++) sumn += h->n1[k];
+    std::vector<const double *> cp(d + 2, nullptr);
+    for (int k = 1; k <= d; k++) cp[k] = core_dev(h, k);
+    std::vector<int> rr(h->rfinal.begin(), h->rfinal.end());
+    double *dw, *dtq, *dout; const double **dcp; int *dr;
+    HIPCHECK(hipMalloc((void **)&dw, sizeof(double) * 2 * sumn * nf)); HIPCHECK(hipMalloc((void **)&dtq, sizeof(double) * (size_t)nf * (d + 1) * 2 * RM * RM));
+    HIPCHECK(hipMalloc((void **)&dout, sizeof(double) * 2 * nf)); HIPCHECK(hipMalloc((void **)&dcp, sizeof(double *) * (d + 2))); HIPCHECK(hipMalloc((void **)&dr, sizeof(int) * (d + 1)));
+    HIPCHECK(hipMemcpy(dw, w, sizeof(double) * 2 * sumn * nf, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dcp, cp.data(), sizeof(double *) * (d + 2), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dr, rr.data(), sizeof(int) * (d + 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_zquad_build, dim3(d, nf), dim3(256), 0, h->stream, d, RM, h->NM, h->P.SS, h->P.n, (const int *)dr, (const double *const *)dcp, (const double *)dw, 2 * sumn, dtq);
+    const size_t lds = sizeof(double) * 4 * (size_t)RM * RM;
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zquad_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_zquad_chain, dim3(nf), dim3(256), lds, h->stream, d, RM, (const int *)dr, (const double *)dtq, dout);
+    HIPCHECK(hipMemcpyAsync(out, dout, sizeof(double) * 2 * nf, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipGetLastError());
+    (void)hipFree(dw); (void)hipFree(dtq); (void)hipFree(dout); (void)hipFree(dcp); (void)hipFree(dr);
+    return TTX_OK;
+}
+
 extern "C" int ttx_ijk(ttx_engine *h, const int32_t *ind, double *val)
 {
     int rc = tt_prepare(h, "dtt_ijk");

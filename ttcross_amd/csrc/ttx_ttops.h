@@ -264,3 +264,50 @@ __global__ void k_transpose(int rows, int cols, const double *in, double *out)
         out[c + (size_t)cols * i] = in[x];
     }
 }
+
+// ztt_quad, batched: T(i,k) = sum_j U(i,j,k) w_j per core and weight set (zgemv order), stored as (re, im) planes.
+// grid (core, weight set), one block each; tq: [nf][d][2][RM*RM]
+__global__ __launch_bounds__(256) void k_zquad_build(int d, int RM, int NM, size_t SS, const int *n1, const int *r, const double *const *cores,
+                                                     const double *w, size_t wstride, double *tq)
+{
+    const int p = blockIdx.x + 1, f = blockIdx.y;
+    const int r0 = r[p - 1], r1 = r[p], n = n1[p];
+    size_t off = 0;
+    for (int c = 1; c < p; c++) off += n1[c];
+    const double *wf = w + (size_t)f * wstride + 2 * off;
+    const double *A = cores[p];
+    double *tr = tq + (((size_t)f * (d + 1) + p) * 2) * RM * RM, *ti = tr + (size_t)RM * RM;
+    for (int x = threadIdx.x; x < r0 * r1; x += blockDim.x) {
+        const int i = x % r0, k = x / r0;
+        const double *a = A + i + SS * k;
+        double yr = 0.0, yi = 0.0;
+        for (int j = 0; j < n; j++) { const double v = a[(size_t)RM * j]; yr = yr + wf[2 * j] * v; yi = yi + wf[2 * j + 1] * v; }
+        tr[i + RM * k] = yr; ti[i + RM * k] = yi;
+    }
+}
+// left-to-right chain of the complex matrices (zgemm 'n','n' order), one block per weight set
+__global__ __launch_bounds__(256) void k_zquad_chain(int d, int RM, const int *r, const double *tq, double *out)
+{
+    extern __shared__ __align__(16) double sh[];     // 4 * RM*RM : prev(re,im), next(re,im)
+    const int f = blockIdx.x, tid = threadIdx.x, mym = r[0];
+    double *pr = sh, *pi = sh + RM * RM, *nr = pi + RM * RM, *ni = nr + RM * RM;
+    const double *t1 = tq + (((size_t)f * (d + 1) + 1) * 2) * RM * RM;
+    for (int x = tid; x < mym * r[1]; x += blockDim.x) { pr[(x % mym) + RM * (x / mym)] = t1[(x % mym) + RM * (x / mym)]; pi[(x % mym) + RM * (x / mym)] = t1[(size_t)RM * RM + (x % mym) + RM * (x / mym)]; }
+    __syncthreads();
+    for (int p = 2; p <= d; p++) {
+        const double *tr = tq + (((size_t)f * (d + 1) + p) * 2) * RM * RM, *ti = tr + (size_t)RM * RM;
+        const int r0 = r[p - 1], r1 = r[p];
+        for (int x = tid; x < mym * r1; x += blockDim.x) {
+            const int i = x % mym, j = x / mym;
+            double cr = 0.0, ci = 0.0;
+            for (int l = 0; l < r0; l++) {          // c += temp * a, temp = curr(l,j), a = prev(i,l)
+                const double br = tr[l + RM * j], bi = ti[l + RM * j], ar = pr[i + RM * l], ai = pi[i + RM * l];
+                cr = cr + (br * ar - bi * ai); ci = ci + (br * ai + bi * ar);
+            }
+            nr[i + RM * j] = cr; ni[i + RM * j] = ci;
+        }
+        __syncthreads();
+        double *t = pr; pr = nr; nr = t; t = pi; pi = ni; ni = t;
+    }
+    if (tid == 0) { out[2 * f] = pr[0]; out[2 * f + 1] = pi[0]; }
+}

@@ -87,6 +87,7 @@ def load_library():
     L.ttx_norm.argtypes = [c_void_p, c_double, POINTER(c_double)]
     L.ttx_dot.argtypes = [c_void_p, c_void_p, POINTER(c_double)]
     L.ttx_ijk.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_double)]
+    L.ttx_zquad.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
     L.ttx_accchk.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int32)]
     L.ttx_kernel_stats.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
     L.ttx_k_residual_argmax.argtypes = [c_int32, c_int32, c_int32, POINTER(c_double), POINTER(c_double),
@@ -297,6 +298,13 @@ class TTCross:
         v = c_double()
         _check(load_library().ttx_dot(self._h, other._h, ctypes.byref(v)))
         return v.value
+
+    def zquad(self, w):
+        """ztt_quad (lib/dmrgg.f90:1418) batched: w complex array (nf, sum(n)) of rank-1 weights; returns nf complex values."""
+        ww = np.ascontiguousarray(np.atleast_2d(np.asarray(w, dtype=np.complex128)))
+        out = np.zeros(2 * ww.shape[0])
+        _check(load_library().ttx_zquad(self._h, ww.shape[0], _dp(ww.view(np.float64)), _dp(out)))
+        return out.view(np.complex128).copy()
 
     def tijk(self, ind):
         a = np.ascontiguousarray(ind, dtype=np.int32)
