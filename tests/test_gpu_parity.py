@@ -282,3 +282,16 @@ def test_zquad_complex_weights():
     for k in range(8):
         want = complex(float(ref[k][2]), float(ref[k][3]))
         assert abs(got[k] - want) <= 1e-12 * abs(want)
+
+
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("kind,m,n,r,piv,nproc", [("c", 16, 51, 32, 2, 1), ("c", 64, 51, 32, 2, 8), ("c", 8, 25, 12, 3, 2), ("c", 5, 17, 8, 0, 1)])
+def test_both_sweep_paths_bit_exact(monkeypatch, fused, kind, m, n, r, piv, nproc):
+    """The multi-kernel sweep (TTX_FUSED=0) and the whole-sweep fused kernel (TTX_FUSED=1) against the oracle."""
+    monkeypatch.setenv("TTX_FUSED", fused)
+    s = D.ising_setup(kind, m, n)
+    tt, oo = _run_both(s, r, piv, nproc=nproc)
+    assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d])
+    assert [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]]
+    assert [a["neval"] for a in tt.sweeps()] == [b["neval"] for b in oo["sweeps"]]
+    assert tt.quad(s["quad"]) == oo["value"]

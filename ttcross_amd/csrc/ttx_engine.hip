@@ -22,6 +22,7 @@
 #include "../../include/ttx.h"
 #include "ttx_kernels.h"
 #include "ttx_ttops.h"
+#include "ttx_fused.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const char *fmt, ...)
@@ -106,6 +107,8 @@ struct ttx_engine {
     int *Si = nullptr;
     size_t lds_half = 0, lds_lot = 0, lds_par = 0;
     int lot_batch = 1, half_vals = 0;
+    int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
+    size_t lds_fused = 0;
 };
 
 template <class T>
@@ -114,6 +117,9 @@ static int dev_alloc(ttx_engine *h, T **p, size_t count)
     void *q = nullptr;
     HIPCHECK(hipMalloc(&q, count * sizeof(T) + 64));
     HIPCHECK(hipMemset(q, 0, count * sizeof(T) + 64));
+    // the fill runs on the null stream, which is NOT ordered against the engine's non-blocking stream: finish it
+    // here, or a buffer allocated on first use could be zeroed after the first kernel has written it
+    HIPCHECK(hipDeviceSynchronize());
     h->allocs.push_back(q);
     *p = (T *)q;
     return TTX_OK;
@@ -280,6 +286,15 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
         const int nlotmax = 2 * h->RM + 2 * NM;
         const size_t VS = ((d + 7) & ~7) + 8;
         h->lds_lot = sizeof(double) * (cfg->npar + 4) + sizeof(int) * 4 * (nlotmax + 4) + sizeof(short) * (2 * RM * VS + 16);
+    }
+    {   // whole-sweep fused kernel: Ising C, rank <= one wave, everything of a bond step in one CU's LDS
+        const size_t VS = ((d + 7) & ~7) + 8;
+        const int nlotmax = 2 * h->RM + 2 * NM;
+        h->lds_fused = sizeof(double) * (cfg->npar + 4 + 4 * RM * VS + 2 * RM * NM + RM + 4) + sizeof(int) * 4 * (nlotmax + 4);
+        const char *env = getenv("TTX_FUSED");
+        const bool want = env ? atoi(env) != 0 : (h->G == 1);   // measured: wins for one group, loses when 8 groups share a launch
+        h->fused = want && cfg->fun_id == TTX_FUN_ISING && P.ising_id == 1 && cfg->pivoting >= 0 && h->RM <= 64 && nlotmax <= FB &&
+                   P.cdf_tab != nullptr && h->lds_fused <= 150 * 1024;
     }
     if (h->lds_half > 160 * 1024 || h->lds_lot > 120 * 1024) { ttx_destroy(h); return fail(TTX_EINVAL, "problem too large for LDS staging (d*maxrank)"); }
     *out = h;
@@ -515,6 +530,7 @@ static int run_impl(ttx_engine *h)
     // kernels that may stage more than the default 64 KB of dynamic LDS (160 KB per CU on gfx950)
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_halfstep<FUN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_half));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lottery<FUN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_lot));
+    if (h->fused) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fused));
     // ---- reset state (lib/dmrgg.f90:96-100, 141-148, 279-288) ----
     {
         std::vector<GroupState> gs(G);
@@ -563,7 +579,11 @@ static int run_impl(ttx_engine *h)
     while (!ready) {
         it++;
         const int dir = 2 - it % 2;
-        for (int pp = 1; pp <= h->nbmax; pp++) {
+        if (h->fused) {
+            KScope ks(h, TTX_K_HALFSTEP, 1);
+            hipLaunchKernelGGL(k_sweep_fused, dim3(G), dim3(FB), h->lds_fused, st, P, dir, h->nbmax);
+        }
+        for (int pp = 1; pp <= h->nbmax && !h->fused; pp++) {
             if (h->cfg.pivoting >= 0) {
                 { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp); }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
