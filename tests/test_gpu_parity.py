@@ -295,3 +295,18 @@ def test_both_sweep_paths_bit_exact(monkeypatch, fused, kind, m, n, r, piv, npro
     assert [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]]
     assert [a["neval"] for a in tt.sweeps()] == [b["neval"] for b in oo["sweeps"]]
     assert tt.quad(s["quad"]) == oo["value"]
+
+
+def test_full_size_d256_against_reference_value():
+    """BASELINE config 5 at FULL size (Ising D_256, n=101, r=64, PIV=5; 255 cores, 7.4e7 O(d^2) evaluations), 8 bond
+    groups on one GPU.  No oracle run at this size (minutes of CPU): the size-independent property is the integral
+    itself -- BASELINE.md's value of the genuine reference (8 ranks: 0.30027620068537628e-1, 1 rank: ...538038e-1;
+    they differ by 1.4e-14) -- plus the reference's own stop behaviour (38 sweeps to maxrank... 63 would be the cap;
+    the accuracy rule never fires here) and the evaluation count within 0.1 % of the reference's 73 621 774."""
+    s = D.ising_setup("d", 256, 101)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], 64, pivoting=5, accuracy=s["acc"], quad=s["quad"], nproc=8).run()
+    v = tt.quad(s["quad"])
+    assert abs(v - 0.030027620068538038) <= 1e-12 * abs(v)
+    assert abs(tt.neval - 73621774) <= 1e-3 * 73621774
+    acc = tt.accchk(2000)
+    assert acc["einf"] <= 1e-9 * acc["ainf"]
