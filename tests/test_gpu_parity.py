@@ -310,3 +310,38 @@ def test_full_size_d256_against_reference_value():
     assert abs(tt.neval - 73621774) <= 1e-3 * 73621774
     acc = tt.accchk(2000)
     assert acc["einf"] <= 1e-9 * acc["ainf"]
+
+
+def _ising_problem(n_list, ident=1.0):
+    """Ising-type problem with RAGGED mode sizes (the API allows arg%n(p) to differ; n(1) must be the largest because
+    the integrand addresses the weights at par(n(1)+ind), test_crs_ising.f90:181-183)."""
+    nmax = n_list[0]
+    x, w = D.lgwt(nmax)
+    par = np.zeros(2 * nmax + 1)
+    par[:nmax] = (x + 1.0) / 2
+    par[nmax:2 * nmax] = 0.5 * w * float(nmax // 2)
+    par[2 * nmax] = ident
+    quad = [np.full(n, 1.0 / float(nmax // 2)) for n in n_list]
+    return dict(n=list(n_list), par=par, quad=quad, fun_id=E.TTX_FUN_ISING, aux=None, acc=500 * D.EPS, tru=None)
+
+
+EDGE = [("ragged_c", [17, 9, 13, 17, 11], 1.0, 8, 2, 1), ("ragged_c_groups", [17, 9, 13, 17, 11, 5, 16], 1.0, 7, 2, 3),
+        ("ragged_d", [15, 7, 11, 15], 2.0, 6, 3, 1), ("d2", [21, 21], 1.0, 9, 2, 1), ("d3_two_groups", [13, 13, 13], 1.0, 6, 1, 2),
+        ("maxrank1", [17, 17, 17, 17], 1.0, 1, 2, 1), ("saturating", [3, 3, 3, 3], 1.0, 12, 2, 1), ("maxrank2", [9, 9, 9], 3.0, 2, 0, 1)]
+
+
+@pytest.mark.parametrize("name,n_list,ident,r,piv,nproc", EDGE, ids=[e[0] for e in EDGE])
+def test_edge_cases_bit_exact(name, n_list, ident, r, piv, nproc):
+    """Ragged mode sizes, the smallest trains (d = 2, 3), maxrank = 1 (no sweep at all), ranks that saturate below
+    maxrank (every later pivot is rejected by the threshold test, lib/dmrgg.f90:599-600)."""
+    s = _ising_problem(n_list, ident)
+    tt, oo = _run_both(s, r, piv, nproc=nproc)
+    gs, os_ = tt.sweeps(), oo["sweeps"]
+    assert len(gs) == len(os_)
+    assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d])
+    for a, b in zip(gs, os_):
+        assert (a["neval"], a["erank"], a["val"], a["amax"], a["pivotmax"]) == (b["neval"], b["erank"], b["val"], b["amax"], b["pivotmax"])
+    assert np.array_equal(tt.ranks(), oo["r"])
+    for k in range(1, tt.d + 1):
+        assert np.array_equal(tt.core(k), oo["cores"][k - 1])
+    assert tt.quad(s["quad"]) == oo["value"]
