@@ -55,7 +55,7 @@ typedef struct ttx_config {
     int32_t world_rank;     /* this process within the multi-GPU job (0 when single process)         */
     int32_t world_size;     /* number of processes (GPUs); groups are split contiguously over them   */
     int32_t verbose;        /* 1: print the reference's per-sweep log lines (lib/dmrgg.f90:971-1008) */
-    int32_t use_graph;      /* 1: replay each sweep as a captured hipGraph                           */
+    int32_t use_graph;      /* reserved (the sweep is GPU-bound back to back; graph replay is not used)   */
 } ttx_config;
 
 /* one line of the reference's per-sweep report (lib/dmrgg.f90:971-1008) */

@@ -106,7 +106,7 @@ struct ttx_engine {
     double *Wa = nullptr, *Wb = nullptr, *Wc = nullptr, *Wd = nullptr, *Sm = nullptr, *bak = nullptr;
     int *Si = nullptr;
     size_t lds_half = 0, lds_lot = 0, lds_par = 0;
-    int lot_batch = 1, half_vals = 0;
+    int half_vals = 0;
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
 };

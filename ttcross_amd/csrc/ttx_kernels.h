@@ -1143,18 +1143,6 @@ __global__ void k_exch_localmax(DevProb P)
     for (int g = 0; g < P.G; g++) { a = fmax(a, P.red[4 * g]); b = fmax(b, P.red[4 * g + 1]); c = fmax(c, P.red[4 * g + 2]); }
     P.redsend[0] = a; P.redsend[1] = b; P.redsend[2] = c; P.redsend[3] = 0.0;
 }
-// stage 2 (after the RCCL all-reduce over GPUs, or directly when there is one GPU): :867-870 and :961
-__global__ void k_exch_max(DevProb P)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double a = P.redrecv[0], b = P.redrecv[1], c = P.redrecv[2];
-    for (int g = 0; g < P.G; g++) {
-        GroupState &gs = P.gs[g];
-        gs.amax = a; gs.pivotmax = b; gs.pivotmin = (-c == 999e9) ? -1.0 : -c;
-        gs.pivotmax_prev = b;
-    }
-}
-
 // apply the neighbours' pivots: ranks, index tables, inv of the left boundary bond (:822-850, :1209-1246)
 __device__ __forceinline__ void exch_apply_group(const DevProb &P, int g)
 {

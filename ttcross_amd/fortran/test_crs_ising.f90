@@ -19,16 +19,7 @@ program main
  call readarg(1,a,'c'); call readarg(2,m,6); call readarg(3,n,65); call readarg(4,r,20); call readarg(5,piv,1)
  call mpi_init(info); call mpi_comm_size(MPI_COMM_WORLD,nproc,info); call mpi_comm_rank(MPI_COMM_WORLD,me,info)
  adj=0; if(mod(n,2).eq.0)then; n=n+1; adj=1; endif
- write(*,'(a)') 'Hi, this is TT cross interpolation computing Ising integral...'
- write(*,'(3x,a,a10)') 'integral :',a
- write(*,'(3x,a,i10)') 'dimension:',m
- if(adj.eq.0)then; write(*,'(3x,a,i10)') 'quadratur:',n; else; write(*,'(3x,a,i10,a)') 'quadratur:',n,' (adjusted)'; endif
- write(*,'(3x,a,i10)') 'TT ranks :',r
- write(*,'(3x,a,i10)') 'pivoting :',piv
- write(*,'(3x,a,i10)') 'MPI procs:',nproc
- write(*,'(3x,a,a10)') 'engine   :','MI355X HIP'
- write(*,'(3x,a,i10)') 'sizeof(d):',storage_size(1.d0)
- write(*,'(3x,a,e10.3)') 'epsilon  :',epsilon(1.d0)
+ call banner()
  acc=500*epsilon(1.d0)
  allocate(par(2*n+1))
  select case(a)
@@ -69,6 +60,23 @@ program main
  call dealloc(tt)
  call mpi_finalize(info)
 contains
+ subroutine banner()
+  ! the reference driver's header, line for line (values only differ in the engine line)
+  character(len=9),parameter :: lab(6) = ['dimension','quadratur','TT ranks ','pivoting ','MPI procs','sizeof(d)']
+  integer :: val(6),q
+  val = [m, n, r, piv, nproc, storage_size(1.d0)]
+  write(*,'(a)') 'Hi, this is TT cross interpolation computing Ising integral...'
+  write(*,'(3x,a,a10)') 'integral :',a
+  do q = 1, 6
+   if(q == 2 .and. adj /= 0) then
+    write(*,'(3x,a,a,i10,a)') lab(q),':',val(q),' (adjusted)'
+   else
+    write(*,'(3x,a,a,i10)') lab(q),':',val(q)
+   end if
+   if(q == 5) write(*,'(3x,a,a10)') 'engine   :','MI355X HIP'
+  end do
+  write(*,'(3x,a,e10.3)') 'epsilon  :',epsilon(1.d0)
+ end subroutine
  double precision function ising_value(a,m) result(t)
   ! Bailey, Borwein & Crandall, "Integrals of the Ising class" (2006), rounded to double
   character(len=1),intent(in) :: a

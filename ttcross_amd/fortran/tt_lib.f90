@@ -36,34 +36,53 @@ module tt_lib
  interface tijk;        module procedure dtt_ijk;  end interface
 contains
  subroutine dtt_alloc(arg)
+  ! (re)allocate every core k = l..m with the shape (r(k-1), n(k), r(k))
   type(dtt),intent(inout) :: arg
-  integer :: i,info
-  if(arg%m.lt.arg%l)return
-  if(arg%l.le.0)then;write(*,*)'dtt_alloc: %l should be > 0';stop;endif
-  if(arg%m.gt.tt_size)then;write(*,*)'dtt_alloc: %m exceeds tt_size, change parameter and recompile!';stop;endif
-  do i=arg%l,arg%m
-   if(associated(arg%u(i)%p))deallocate(arg%u(i)%p)
-   allocate(arg%u(i)%p(arg%r(i-1),arg%n(i),arg%r(i)),stat=info)
-   if(info.ne.0)then;write(*,*)'TT allocate fail: no memory';stop;endif
-  end do
+  integer :: k,ierr
+  if(arg%m < arg%l) return
+  if(arg%l < 1) then
+   write(*,*) 'dtt_alloc: %l should be > 0'; stop
+  end if
+  if(arg%m > tt_size) then
+   write(*,*) 'dtt_alloc: %m exceeds tt_size, change parameter and recompile!'; stop
+  end if
+  cores: do k = arg%l, arg%m
+   if(associated(arg%u(k)%p)) deallocate(arg%u(k)%p)
+   allocate(arg%u(k)%p(arg%r(k-1), arg%n(k), arg%r(k)), stat=ierr)
+   if(ierr /= 0) then
+    write(*,*) 'TT allocate fail: no memory'; stop
+   end if
+  end do cores
  end subroutine
+
  subroutine dtt_dealloc(arg)
+  ! free the host cores and release the device engine that holds the resident train
   use ttx_c, only: ttx_destroy
   type(dtt),intent(inout) :: arg
-  integer :: i
-  do i=1,tt_size
-   if(associated(arg%u(i)%p))deallocate(arg%u(i)%p)
+  integer :: k
+  do k = 1, tt_size
+   if(associated(arg%u(k)%p)) then
+    deallocate(arg%u(k)%p); nullify(arg%u(k)%p)
+   end if
   end do
-  if(c_associated(arg%ttx))then; call ttx_destroy(arg%ttx); arg%ttx=c_null_ptr; endif
+  if(c_associated(arg%ttx)) then
+   call ttx_destroy(arg%ttx)
+   arg%ttx = c_null_ptr
+  end if
  end subroutine
+
  subroutine dtt_ones(arg)
+  ! rank-one train of ones
   type(dtt),intent(inout) :: arg
   integer :: k
-  if(arg%m.lt.arg%l)return
-  arg%r(arg%l-1:arg%m)=1
+  if(arg%m < arg%l) return
+  arg%r(arg%l-1:arg%m) = 1
   call dtt_alloc(arg)
-  do k=arg%l,arg%m; arg%u(k)%p=1.d0; end do
+  do k = arg%l, arg%m
+   arg%u(k)%p(:,:,:) = 1.d0
+  end do
  end subroutine
+
  subroutine dtt_pull(arg)
   ! refresh arg%r and arg%u from the device-resident tensor train
   use ttx_c
@@ -115,18 +134,29 @@ contains
   ix=ind(1:arg%m)
   call dtt_resident(arg,'dtt_ijk'); call ttx_check(ttx_ijk(arg%ttx,ix,a),'dtt_ijk')
  end function
- double precision function dtt_rank(arg) result(r)
+ double precision function dtt_rank(arg) result(er)
+  ! effective rank: the r for which a train with all inner ranks r stores as many numbers as arg does,
+  ! i.e. the positive root of  a r^2 + b r - S = 0,  S = sum r(k-1) n(k) r(k)
   type(dtt),intent(in) :: arg
-  integer :: l,m,i,a,b,d
-  l=arg%l;m=arg%m;d=m-l+1
-  if(d.le.0)then;r=-1.d0;return;endif
-  if(d.eq.1)then;r=0.d0;return;endif
-  r=0.d0
-  do i=l,m; r=r+arg%r(i-1)*arg%n(i)*arg%r(i); end do
-  if(r.eq.0.d0)return
-  b=arg%r(l-1)*arg%n(l)+arg%n(m)*arg%r(m)
-  if(d.eq.2)then;r=r/b;return;endif
-  a=sum(arg%n(l+1:m-1))
-  r=(dsqrt(b*b+4.d0*a*r)-b)/(2.d0*a)
+  integer :: k,first,last,ncores,inner,edge
+  double precision :: stored
+  first = arg%l; last = arg%m; ncores = last-first+1
+  er = -1.d0
+  if(ncores <= 0) return
+  er = 0.d0
+  if(ncores == 1) return
+  stored = 0.d0
+  do k = first, last
+   stored = stored + arg%r(k-1)*arg%n(k)*arg%r(k)
+  end do
+  er = stored
+  if(stored == 0.d0) return
+  edge = arg%r(first-1)*arg%n(first) + arg%n(last)*arg%r(last)
+  if(ncores == 2) then
+   er = stored/edge
+   return
+  end if
+  inner = sum(arg%n(first+1:last-1))
+  er = (dsqrt(edge*edge + 4.d0*inner*stored) - edge)/(2.d0*inner)
  end function
 end module
