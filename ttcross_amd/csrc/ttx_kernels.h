@@ -155,6 +155,80 @@ __device__ __forceinline__ void chain8(const short *p, int n, const double *tab,
     }
 }
 
+// ---- Ising D / E (id 2, 3) over aligned index rows ----------------------------------------------------------
+// The O(d^2) product a = prod_{i<j} ((u_ij-1)/(u_ij+1))^2 (test_crs_ising.f90:186-195) is one IEEE division per
+// step on a sequential chain; the generic accessor exposed two dependent LDS latencies (index, node value) plus
+// scalar control flow in every step.  Here the dims are walked as branch-free ranges of the staged rows with
+// 8-wide chunk loads (one 128-bit index read + 8 independent table reads ahead of the 8 dependent steps).
+// Layout: dims 1..A from pa, then NS explicit dims (s1[, s2]), then dims A+NS+1..m from pb.
+template <class STEP>
+__device__ __forceinline__ void seg_range(const short *p, int lo, int hi, const double *tab, STEP step)
+{   // elements [lo, hi) of an aligned, padded row, ascending
+#pragma unroll 2
+    for (int c = lo & ~7; c < hi; c += 8) {
+        Short8 ix = ld8(p + c); double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = tab[ix.v[k]];
+        if (c >= lo && c + 8 <= hi) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) step(x[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (c + k >= lo && c + k < hi) step(x[k]);
+        }
+    }
+}
+template <int NS, class STEP>
+__device__ __forceinline__ void dims_asc(const short *pa, int A, int s1, int s2, const short *pb, int m, const double *tab,
+                                         int jlo, int jhi, STEP step)
+{   // dims jlo..jhi (1-based, inclusive), ascending
+    if (jlo > jhi) return;
+    const int a1 = jhi < A ? jhi : A;
+    if (jlo <= a1) seg_range(pa, jlo - 1, a1, tab, step);
+    if (jlo <= A + 1 && A + 1 <= jhi) step(tab[s1]);
+    if (NS == 2 && jlo <= A + 2 && A + 2 <= jhi) step(tab[s2]);
+    const int b0 = jlo > A + NS + 1 ? jlo : A + NS + 1;
+    if (b0 <= jhi) seg_range(pb, b0 - A - NS - 1, jhi - A - NS, tab, step);
+}
+template <int NS>
+__device__ __forceinline__ double f_ising_de(int id, int m, int n1, const double *par, const short *pa, int A, int s1, int s2, const short *pb)
+{
+    const double *nodes = par - 1, *weights = par + n1 - 1;
+    const int nb = m - A - NS;
+    double a = 1.0, b = 0.0;
+    for (int i = 0; i <= m; i++) {                                   // :186-195
+        double uij = 1.0;
+        const int jlo = i + 1, jhi = m;
+        if (jlo > jhi) continue;
+        dims_asc<NS>(pa, A, s1, s2, pb, m, nodes, jlo, jhi, [&](double xv) {
+            uij = uij * xv;
+            const double t = (uij - 1.0) / (uij + 1.0);
+            a = a * (t * t);
+        });
+    }
+    if (id == 2) {                                                   // :197-205
+        double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
+        auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
+        auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
+        chain8<true>(pb, nb, nodes, vstep);
+        if (NS == 2) vstep(nodes[s2]);
+        vstep(nodes[s1]);
+        chain8<true>(pa, A, nodes, vstep);
+        chain8<false>(pa, A, nodes, wstep);
+        wstep(nodes[s1]);
+        if (NS == 2) wstep(nodes[s2]);
+        chain8<false>(pb, nb, nodes, wstep);
+        b = 1.0 / (v * w);
+    }
+    double f = (id == 2) ? 2 * a * b : 2 * a;
+    auto fstep = [&](double xv) { f = f * xv; };
+    chain8<false>(pa, A, weights, fstep);
+    fstep(weights[s1]);
+    if (NS == 2) fstep(weights[s2]);
+    chain8<false>(pb, nb, weights, fstep);
+    return f;
+}
+
 // Ising C (id 1) over aligned rows.  Same arithmetic as f_ising: the v- and w-recurrences of
 // test_crs_ising.f90:199-204 are independent, so they run as separate loops.
 __device__ __forceinline__ double f_ising_c3(int m, int n1, const double *par, const Src3 &S)
@@ -203,6 +277,7 @@ template <int FUN>
 __device__ __forceinline__ double eval_src4(const DevProb &P, const double *par, const Src4 &S)
 {
     if (FUN == FUN_ISING && P.ising_id == 1) return f_ising_c4(P.d, P.n[1], par, S);
+    if (FUN == FUN_ISING) return f_ising_de<2>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.s1, S.s2, S.pb);
     return eval_fun<FUN>(P, par, S);
 }
 
@@ -267,6 +342,7 @@ template <int FUN, bool ALIGNED>
 __device__ __forceinline__ double eval_src3(const DevProb &P, const double *par, const Src3 &S)
 {
     if (ALIGNED && FUN == FUN_ISING && P.ising_id == 1) return f_ising_c3(P.d, P.n[1], par, S);
+    if (ALIGNED && FUN == FUN_ISING) return f_ising_de<1>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.self, 0, S.pb);
     return eval_fun<FUN>(P, par, S);
 }
 
