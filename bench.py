@@ -108,7 +108,11 @@ def main():
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            gloo_pg = dist.new_group(backend="gloo")
+            try:        # only needed if the in-library RCCL transport cannot be brought up
+                gloo_pg = dist.new_group(backend="gloo")
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] no gloo group for the fallback transport: {e}", file=sys.stderr, flush=True)
+                gloo_pg = None
 
     from ttcross_amd import drivers as D
     from ttcross_amd import engine as E
@@ -141,6 +145,8 @@ def main():
             tt.close()
             tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
                            nproc=groups, device=local, world_rank=rank, world_size=world)
+            if a.backend == "nccl" and gloo_pg is None:
+                raise SystemExit("neither the RCCL transport nor a gloo fallback group is available")
             tt.set_dist_transport(dist, group=gloo_pg)
             transport = "gloo host-staged fallback"
 
