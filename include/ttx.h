@@ -131,6 +131,20 @@ int ttx_ijk(ttx_engine *h, const int32_t *ind, double *val);
  * doubles, out = nf (re, im) pairs.  Single-process engines only. */
 int ttx_zquad(ttx_engine *h, int32_t nf, const double *w, double *out);
 
+/* Tensor trains that do not come from a sweep.
+ * ttx_from_tt : upload a train given as compact column-major cores (d blocks r(k-1)*n(k)*r(k), concatenated) and make
+ *               it the resident train of a new single-process engine (the reference: plain assignment into arg%u(k)%p);
+ *               all of ttx_get_*, ttx_quad, ttx_zquad and the tt_lib utilities work on it; ttx_run / ttx_accchk do not
+ *               (no integrand).  ranks must be <= 128.
+ * ttx_write   : dtt_write (lib/ttio.f90:29-108), the reference's raw stream file: 128-byte header `tthead`
+ *               (lib/ttio.f90:10-17), l, m, n(l:m), r(l-1:m) as int32, all cores as float64; l = 1.
+ * ttx_read    : dtt_read (lib/ttio.f90:196-297) of such a file into a new engine (checks 'TT' and version 1).
+ * ttx_get_modes: arg%m and arg%n(1:m) of an engine (n may be NULL). */
+int ttx_from_tt(ttx_engine **out, int32_t d, const int32_t *n, const int32_t *r, const double *cores, int32_t device);
+int ttx_write(const ttx_engine *h, const char *path);
+int ttx_read(ttx_engine **out, const char *path, int32_t device);
+int ttx_get_modes(const ttx_engine *h, int32_t *d, int32_t *n);
+
 /* profiling: with on != 0 the next ttx_run brackets every kernel launch with HIP events on the engine's
  * stream; ttx_kernel_stats then reports, per kernel kind, launches and total milliseconds. */
 #define TTX_K_LOTTERY 0

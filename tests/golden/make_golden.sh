@@ -55,3 +55,9 @@ amdflang -O2 -fopenmp -I/opt/conda/include -Ioracle/_ref/mod tests/golden/ref_zq
   -o oracle/_ref/ref_zquad -L/opt/conda/lib -lmpifort -lmpi -lmkl_rt -Wl,-rpath,/opt/conda/lib -Wl,-rpath,/opt/rocm/lib/llvm/lib 2>/dev/null
 oracle/_ref/ref_zquad 6 33 12 2 | grep zquad > $G/zquad_C_6_33_12_2.txt
 rm -f *.mod
+# dtt_write / dtt_read stream format (lib/ttio.f90) of the genuine reference: a 724-byte file with closed-form cores
+amdflang -O2 -Ioracle/_ref/mod -c /root/reference/lib/ttio.f90 -o oracle/_ref/obj/ttio.o && mv ttio_lib.mod oracle/_ref/mod/
+amdflang -O2 -fopenmp -I/opt/conda/include -Ioracle/_ref/mod tests/golden/ref_ttio.f90 oracle/_ref/obj/{ttio,zero,nan,trans,default,timef,say,rnd,ptype,ort,lr,mat,quad,tt}.o \
+  -o oracle/_ref/ref_ttio -L/opt/conda/lib -lmpifort -lmpi -lmkl_rt -Wl,-rpath,/opt/conda/lib -Wl,-rpath,/opt/rocm/lib/llvm/lib 2>/dev/null
+oracle/_ref/ref_ttio $G/ttio_5.tt $G/ttio_5.tt | grep -E "info|lm|^n|^r|checksum" > $G/ttio_5.txt
+rm -f *.mod

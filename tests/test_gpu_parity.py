@@ -345,3 +345,106 @@ def test_edge_cases_bit_exact(name, n_list, ident, r, piv, nproc):
     for k in range(1, tt.d + 1):
         assert np.array_equal(tt.core(k), oo["cores"][k - 1])
     assert tt.quad(s["quad"]) == oo["value"]
+
+
+# ---- N3: trains from outside the sweep (ttx_from_tt) and the reference's stream file (lib/ttio.f90) -----------------
+def _rand_tt(seed, n, r):
+    rng = np.random.default_rng(seed)
+    return [rng.standard_normal((r[k], n[k], r[k + 1])) for k in range(len(n))]
+
+
+def test_stream_file_read_write_against_reference_file(tmp_path):
+    """ttx_read of the file the GENUINE reference wrote (tests/golden/ttio_5.tt) must give its closed-form cores exactly;
+    ttx_write must reproduce the file byte for byte (apart from header bytes the reference never sets)."""
+    import os
+    from golden_util import GOLDEN
+    from test_host_cpu import _closed_form_cores
+    from ttcross_amd import ttio
+    gold = os.path.join(GOLDEN, "ttio_5.tt")
+    tt = E.TTCross.read(gold)
+    assert tt.d == 5 and list(tt.ranks()) == [1, 2, 3, 2, 2, 1]
+    want = _closed_form_cores()
+    assert all(np.array_equal(tt.core(k), want[k - 1]) for k in range(1, 6))
+    out = tmp_path / "dev.tt"
+    tt.write(out)
+    assert ttio.same_file(out, gold)
+    # a train read from disk is resident: quadrature, element access and norm work on it
+    full = _full(want)
+    assert abs(tt.quad() - full.sum()) <= 1e-12 * abs(full.sum())
+    assert abs(tt.norm() - np.linalg.norm(full)) <= 1e-12 * np.linalg.norm(full)
+    assert abs(tt.tijk([2, 3, 1, 4, 2]) - full[1, 2, 0, 3, 1]) <= 1e-13 * abs(full[1, 2, 0, 3, 1])
+    with pytest.raises(E.TTXError, match="no integrand"):
+        tt.run()
+    with pytest.raises(E.TTXError, match="no integrand"):
+        tt.accchk(10)
+    with pytest.raises(E.TTXError, match="not exist"):
+        E.TTCross.read(tmp_path / "missing.tt")
+    bad = tmp_path / "bad.tt"
+    bad.write_bytes(b"XX" + open(gold, "rb").read()[2:])
+    with pytest.raises(E.TTXError, match="not TT header"):
+        E.TTCross.read(bad)
+    bad.write_bytes(open(gold, "rb").read()[:300])
+    with pytest.raises(E.TTXError, match="error reading cores"):
+        E.TTCross.read(bad)
+
+
+@pytest.mark.parametrize("seed,n,r", [(1, [4, 5, 3, 6], [1, 3, 7, 4, 1]), (2, [7] * 9, [1, 5, 9, 12, 12, 12, 12, 9, 5, 1]),
+                                      (3, [33] * 5, [1, 16, 24, 24, 16, 1]), (4, [2, 3], [1, 2, 1])])
+def test_uploaded_train_roundtrip_and_tt_lib(tmp_path, seed, n, r):
+    """ttx_from_tt: arbitrary (random) trains, not only sweep results, through ort / svd / norm / dot / quad against the
+    oracle's tt_lib restatement (tolerances as in test_tt_ort_svd_norm_dot), plus file round trip (bit-exact)."""
+    cores = _rand_tt(seed, n, r)
+    tt = E.TTCross.from_cores(cores)
+    assert list(tt.ranks()) == r
+    assert all(np.array_equal(tt.core(k), cores[k - 1]) for k in range(1, len(n) + 1))
+    f = tmp_path / "t.tt"
+    tt.write(f)
+    t2 = E.TTCross.read(f)
+    assert all(np.array_equal(t2.core(k), cores[k - 1]) for k in range(1, len(n) + 1))
+    ot = O.OracleTT(cores)
+    nrm = ot.norm()
+    assert abs(tt.norm() - nrm) <= 1e-12 * nrm
+    assert abs(tt.dot(t2) - ot.dot(ot)) <= 1e-12 * nrm ** 2
+    w = [np.cos(np.arange(1, nk + 1)) for nk in n]
+    qref = 1.0
+    v = np.ones((1, 1))
+    for k, c in enumerate(cores):
+        v = v @ np.einsum("ijk,j->ik", c, w[k])
+    qref = float(v[0, 0])
+    assert abs(tt.quad(w) - qref) <= 1e-11 * nrm
+    t2.ort()
+    o1 = O.OracleTT(cores)
+    o1.ort()
+    assert np.array_equal(t2.ranks(), o1.ranks)
+    assert abs(t2.norm() - nrm) <= 1e-11 * nrm
+    for tol, rmax in [(1e-2, 0), (1e-10, 0), (1e-12, 3)]:
+        t3 = E.TTCross.from_cores(cores).svd(tol, rmax)
+        o3 = O.OracleTT(cores)
+        o3.svd(tol, rmax)
+        assert np.array_equal(t3.ranks(), o3.ranks), (tol, rmax, t3.ranks(), o3.ranks)
+        assert abs(t3.norm() - o3.norm()) <= 1e-11 * nrm
+        assert abs(tt.dot(t3) - ot.dot(o3)) <= 1e-11 * nrm ** 2
+
+
+def test_fortran_ttio_dropin(tmp_path):
+    """ttio_lib drop-in (ttcross_amd/fortran/ttio_lib.f90): `call read(tt,f)` / `call write(tt,f)` on the reference's file."""
+    import os
+    import subprocess
+    from golden_util import GOLDEN
+    from ttcross_amd import ttio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ttcross_amd", "fortran", "build", "test_ttio")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran layer not built (needs amdflang)")
+    gold = os.path.join(GOLDEN, "ttio_5.tt")
+    p = subprocess.run([exe, gold, str(tmp_path / "copy.tt"), str(tmp_path / "ones.tt")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = {ln.split()[0] + ("_" + ln.split()[1] if ln.split()[1] in ("info", "ones") else ""): ln for ln in p.stdout.splitlines() if ln.strip()}
+    ref = open(os.path.join(GOLDEN, "ttio_5.txt")).read().splitlines()
+    for key in ("lm", "n", "r", "checksum"):
+        assert out[key] == [ln for ln in ref if ln.split()[0] == key][0]
+    assert out["read_info"].split()[-1] == "0" and out["write_info"].split()[-1] == "0"
+    assert out["missing_info"].split()[-1] == "-1"
+    assert ttio.same_file(tmp_path / "copy.tt", gold)
+    l, n, r, cores = ttio.read_tt(tmp_path / "ones.tt")
+    assert list(n) == [2, 3, 4, 5] and list(r) == [1] * 5 and all(np.all(c == 1.0) for c in cores)

@@ -92,3 +92,64 @@ int main(){ static ttx_cdfseg seg[TTX_MAXSEG]; long bad=0; srand(1);
     subprocess.run(["g++", "-O2", "-ffp-contract=off", str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "0"
+
+
+# ---- the reference's stream file (lib/ttio.f90): host reader/writer against the genuine reference ----
+def _closed_form_cores():
+    nn, rr = [3, 4, 2, 5, 3], [1, 2, 3, 2, 2, 1]
+    cores = []
+    for b in range(1, 6):
+        i, j, k = np.meshgrid(np.arange(1, rr[b - 1] + 1), np.arange(1, nn[b - 1] + 1), np.arange(1, rr[b] + 1), indexing="ij")
+        cores.append((3 * i + 5 * j + 7 * k + 11 * b) / 16.0)
+    return cores
+
+
+def test_ttio_stream_format_against_reference_file(tmp_path):
+    """tests/golden/ttio_5.tt was written by the GENUINE reference's dtt_write (tests/golden/ref_ttio.f90)."""
+    from golden_util import GOLDEN
+    from ttcross_amd import ttio
+    gold = os.path.join(GOLDEN, "ttio_5.tt")
+    l, n, r, cores = ttio.read_tt(gold)
+    assert l == 1 and list(n) == [3, 4, 2, 5, 3] and list(r) == [1, 2, 3, 2, 2, 1]
+    want = _closed_form_cores()
+    assert all(np.array_equal(a, b) for a, b in zip(cores, want))
+    # the checksum line the reference's dtt_read printed for the same file
+    txt = dict(line.split(None, 1) for line in open(os.path.join(GOLDEN, "ttio_5.txt")) if not line.startswith(("write", "read")))
+    s = sum(float((c * (np.arange(1, c.shape[0] + 1)[:, None, None] + 2 * np.arange(1, c.shape[1] + 1)[None, :, None]
+                        + 3 * np.arange(1, c.shape[2] + 1)[None, None, :] + 4 * b)).sum()) for b, c in enumerate(cores, 1))
+    assert s == float(txt["checksum"])
+    out = tmp_path / "w.tt"
+    ttio.write_tt(out, want)
+    assert ttio.same_file(out, gold)
+    # error behaviour of dtt_read: missing magic, wrong version (lib/ttio.f90:236-245)
+    b = bytearray(open(gold, "rb").read())
+    bad = tmp_path / "bad.tt"
+    bad.write_bytes(b"XX" + bytes(b[2:]))
+    with pytest.raises(ttio.TTFileError, match="not TT header"):
+        ttio.read_tt(bad)
+    b[8] = 2
+    bad.write_bytes(bytes(b))
+    with pytest.raises(ttio.TTFileError, match="version"):
+        ttio.read_tt(bad)
+    bad.write_bytes(open(gold, "rb").read()[:300])
+    with pytest.raises(ttio.TTFileError, match="cores"):
+        ttio.read_tt(bad)
+
+
+def test_ttio_written_file_is_read_by_genuine_reference(tmp_path):
+    """Where the reference build exists (this container), its own dtt_read must accept a file we wrote."""
+    import subprocess
+    from golden_util import GOLDEN
+    from ttcross_amd import ttio
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_ttio")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_ttio not built (tests/golden/make_golden.sh)")
+    mine = tmp_path / "mine.tt"
+    ttio.write_tt(mine, _closed_form_cores())
+    p = subprocess.run([exe, str(tmp_path / "ref.tt"), str(mine)], capture_output=True, text=True, timeout=60)
+    if p.returncode != 0 and "error while loading shared libraries" in p.stderr:
+        pytest.skip("reference runtime libraries not present")
+    assert p.returncode == 0, p.stderr
+    got = [ln for ln in p.stdout.splitlines() if ln.split()[0] in ("lm", "n", "r", "checksum", "read", "write")]
+    assert got == open(os.path.join(GOLDEN, "ttio_5.txt")).read().splitlines()
+    assert ttio.same_file(tmp_path / "ref.tt", mine)

@@ -141,7 +141,8 @@ static double powi(double a, int b)
     return r;
 }
 
-extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
+// nofun: an engine that only holds a tensor train (ttx_from_tt / ttx_read): no integrand, ttx_run refused
+static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
 {
     if (!out || !cfg) return fail(TTX_EINVAL, "ttx_create: null argument");
     *out = nullptr;
@@ -149,7 +150,8 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     if (cfg->maxrank < 1 || cfg->maxrank > 128) return fail(TTX_EINVAL, "ttx_create: maxrank must be in 1..128 (got %d)", cfg->maxrank);
     if (cfg->pivoting < -1) return fail(TTX_EINVAL, "dtt_dmrgg: unknown pivoting: %d", cfg->pivoting);   // lib/dmrgg.f90:590-592
     if (2 * cfg->pivoting + 2 > TTX_MAXH) return fail(TTX_EINVAL, "dtt_dmrgg: pivoting %d too large", cfg->pivoting);
-    if (cfg->fun_id < 1 || cfg->fun_id > 3) return fail(TTX_EINVAL, "ttx_create: unknown fun_id %d", cfg->fun_id);
+    if (!(nofun && cfg->fun_id == 0) && (cfg->fun_id < 1 || cfg->fun_id > 3)) return fail(TTX_EINVAL, "ttx_create: unknown fun_id %d", cfg->fun_id);
+    if (cfg->npar < 0 || (cfg->npar > 0 && !cfg->par)) return fail(TTX_EINVAL, "ttx_create: par missing");
     const int W = cfg->world_size < 1 ? 1 : cfg->world_size;
     const int nproc = std::max(cfg->nproc < 1 ? 1 : cfg->nproc, 1);
     if (nproc >= cfg->d) return fail(TTX_EINVAL, "nproc exceeds or equal dimension, cannot proceed");   // lib/dmrgg.f90:114-117
@@ -172,7 +174,7 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     for (int k = 1; k <= d; k++) { h->n1[k] = cfg->n[k - 1]; if (cfg->n[k - 1] < 1 || cfg->n[k - 1] > 32000) { delete h; return fail(TTX_EINVAL, "bad mode size"); } NM = std::max(NM, cfg->n[k - 1]); }
     h->NM = NM;
     if ((long long)h->RM * NM > (long long)TTX_MAXPART * TTX_BLK) { delete h; return fail(TTX_EINVAL, "maxrank*n too large"); }
-    h->par.assign(cfg->par, cfg->par + cfg->npar);
+    if (cfg->npar > 0) h->par.assign(cfg->par, cfg->par + cfg->npar);
     if (cfg->aux && cfg->naux > 0) h->aux.assign(cfg->aux, cfg->aux + cfg->naux);
     if (cfg->mybonds) h->own.assign(cfg->mybonds, cfg->mybonds + nproc + 1);
     else share(1, d - 1, nproc, h->own);                               // lib/dmrgg.f90:126-130
@@ -206,7 +208,7 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     A_(dev_alloc(h, &dn, d + 2));
     A_(dev_alloc(h, &dpar, cfg->npar + 1));
     HIPCHECK(hipMemcpy(dn, h->n1.data(), sizeof(int) * (d + 2), hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(dpar, h->par.data(), sizeof(double) * cfg->npar, hipMemcpyHostToDevice));
+    if (cfg->npar > 0) HIPCHECK(hipMemcpy(dpar, h->par.data(), sizeof(double) * cfg->npar, hipMemcpyHostToDevice));
     if (!h->aux.empty()) { A_(dev_alloc(h, &daux, h->aux.size())); HIPCHECK(hipMemcpy(daux, h->aux.data(), sizeof(double) * h->aux.size(), hipMemcpyHostToDevice)); }
     if (cfg->quadw) {
         h->quadw.assign((size_t)(d + 1) * NM, 0.0);
@@ -300,6 +302,7 @@ extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg)
     *out = h;
     return TTX_OK;
 }
+extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg) { return create_impl(out, cfg, false); }
 
 extern "C" void ttx_destroy(ttx_engine *h)
 {
@@ -674,6 +677,7 @@ extern "C" int ttx_run(ttx_engine *h)
 {
     if (!h) return fail(TTX_EINVAL, "ttx_run: null handle");
     HIPCHECK(hipSetDevice(h->cfg.device));
+    if (h->cfg.fun_id == 0) return fail(TTX_ESTATE, "ttx_run: this engine holds a loaded tensor train and has no integrand");
     for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
     switch (h->cfg.fun_id) {
         case TTX_FUN_ISING: return run_impl<FUN_ISING>(h);
@@ -731,6 +735,115 @@ extern "C" int ttx_get_core(const ttx_engine *h, int k, double *buf)
     for (int s = 0; s < r1; s++)
         HIPCHECK(hipMemcpy2D(buf + (size_t)r0 * n * s, sizeof(double) * r0, src + h->P.SS * s, sizeof(double) * h->RM, sizeof(double) * r0, n, hipMemcpyDeviceToHost));
     return TTX_OK;
+}
+
+// ---- tensor trains from outside the sweep: host cores and the reference's stream file ----------------
+extern "C" int ttx_get_modes(const ttx_engine *h, int32_t *d, int32_t *n)
+{
+    if (!h || !d) return fail(TTX_EINVAL, "ttx_get_modes: null argument");
+    *d = h->d;
+    if (n) for (int k = 1; k <= h->d; k++) n[k - 1] = h->n1[k];
+    return TTX_OK;
+}
+
+extern "C" int ttx_from_tt(ttx_engine **out, int32_t d, const int32_t *n, const int32_t *r, const double *cores, int32_t device)
+{
+    if (!out || !n || !r || !cores) return fail(TTX_EINVAL, "ttx_from_tt: null argument");
+    *out = nullptr;
+    if (d < 2) return fail(TTX_EINVAL, "ttx_from_tt: at least two cores are needed (got %d)", d);
+    int rmax = 1;
+    for (int k = 0; k <= d; k++) { if (r[k] < 1) return fail(TTX_EINVAL, "ttx_from_tt: rank r(%d)=%d", k, r[k]); rmax = std::max(rmax, (int)r[k]); }
+    // ort/svd may pass through r(k) = min(r(k-1)*n(k), ...) <= the incoming ranks, so max(r) is enough storage
+    ttx_config c{};
+    c.d = d; c.n = n; c.fun_id = 0; c.accuracy = -1.0; c.maxrank = rmax; c.pivoting = 0; c.nproc = 1; c.device = device; c.world_size = 1;
+    ttx_engine *h = nullptr;
+    int rc = create_impl(&h, &c, true);
+    if (rc) return rc;
+    GroupState *g0 = (GroupState *)calloc(1, sizeof(GroupState));     // only the bond range is read by the quad kernels
+    g0->first = 1; g0->last = d - 1; g0->gglobal = 0;
+    hipError_t e = hipMemcpy(h->P.gs, g0, offsetof(GroupState, S), hipMemcpyHostToDevice);
+    free(g0);
+    if (e != hipSuccess) { ttx_destroy(h); return fail(TTX_EHIP, "ttx_from_tt: %s", hipGetErrorString(e)); }
+    h->rfinal.assign(r, r + d + 1);
+    size_t off = 0;
+    for (int k = 1; k <= d; k++) {
+        const int r0 = r[k - 1], r1 = r[k], nk = n[k - 1];
+        double *dst = h->P.arg + (size_t)(k - 1) * h->P.CS;
+        for (int s = 0; s < r1; s++) {        // compact host -> padded device slabs (inverse of ttx_get_core)
+            e = hipMemcpy2D(dst + h->P.SS * s, sizeof(double) * h->RM, cores + off + (size_t)r0 * nk * s, sizeof(double) * r0, sizeof(double) * r0, nk, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { ttx_destroy(h); return fail(TTX_EHIP, "ttx_from_tt: %s", hipGetErrorString(e)); }
+        }
+        off += (size_t)r0 * nk * r1;
+    }
+    std::vector<int32_t> rr((size_t)(d + 2), 1);
+    for (int p = 0; p <= d; p++) rr[p] = r[p];
+    e = hipMemcpy(h->P.r, rr.data(), sizeof(int32_t) * rr.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { ttx_destroy(h); return fail(TTX_EHIP, "ttx_from_tt: %s", hipGetErrorString(e)); }
+    h->ran = true;
+    *out = h;
+    return TTX_OK;
+}
+
+// lib/ttio.f90:10-17 `tthead`: 'TT      ', ver(2)=(1,0), inf(4)=(tt_size,0,0,0), comment*64, i(8) with i(1:2)=(l,m); 128 bytes
+namespace {
+struct TTFileHead { char txt[8]; int32_t ver[2]; int32_t inf[4]; char comment[64]; int32_t i[8]; };
+static_assert(sizeof(TTFileHead) == 128, "stream header is 128 bytes");
+}
+extern "C" int ttx_write(const ttx_engine *h, const char *path)
+{
+    if (!h || !path || !h->ran) return fail(TTX_ESTATE, "dtt_write: no tensor train to write");
+    if (h->W > 1) return fail(TTX_EINVAL, "dtt_write: single-process engines only");
+    const int d = h->d;
+    size_t sz = 0;
+    for (int k = 1; k <= d; k++) sz += (size_t)h->rfinal[k - 1] * h->n1[k] * h->rfinal[k];
+    if (sz == 0) return fail(TTX_EINVAL, "dtt_write: tt structure has invalid size: 0");      // lib/ttio.f90:60-61
+    std::vector<double> x(sz);
+    size_t off = 0;
+    for (int k = 1; k <= d; k++) { int rc = ttx_get_core(h, k, x.data() + off); if (rc) return rc; off += (size_t)ttx_core_size(h, k); }
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(TTX_EINVAL, "dtt_write: error opening file: %s", path);                // :85-88
+    TTFileHead hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.txt, "TT      ", 8);
+    hd.ver[0] = 1; hd.ver[1] = 0; hd.inf[0] = 2048;
+    hd.i[0] = 1; hd.i[1] = d;
+    const int32_t lm[2] = {1, d};
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(lm, sizeof lm, 1, f) == 1;          // :75-76
+    ok = ok && fwrite(&h->n1[1], sizeof(int32_t), d, f) == (size_t)d && fwrite(h->rfinal.data(), sizeof(int32_t), d + 1, f) == (size_t)d + 1;   // :77
+    ok = ok && fwrite(x.data(), sizeof(double), sz, f) == sz;                                 // :78
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(TTX_EINVAL, "dtt_write: error writing file: %s", path);
+    return TTX_OK;
+}
+
+extern "C" int ttx_read(ttx_engine **out, const char *path, int32_t device)
+{
+    if (!out || !path) return fail(TTX_EINVAL, "dtt_read: null argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(TTX_EINVAL, "dtt_read: file not exist: %s", path);                     // lib/ttio.f90:210-214
+    TTFileHead hd;
+    int32_t lm[2];
+    auto bad = [&](const char *what) { fclose(f); return fail(TTX_EINVAL, "dtt_read: %s: %s", what, path); };
+    if (fread(&hd, sizeof hd, 1, f) != 1) return bad("error reading header");                // :276-279
+    if (hd.txt[0] != 'T' || hd.txt[1] != 'T') return bad("not TT header in file");            // :236-240
+    if (hd.ver[0] != 1) return bad("not correct version of TT file");                         // :241-245
+    if (fread(lm, sizeof lm, 1, f) != 1) return bad("error reading lm");
+    const int l = lm[0], m = lm[1];
+    if (l < 1 || m < l || m > 2048) return bad("read strange l,m");                           // :249-251, tt_size
+    const int d = m - l + 1;
+    std::vector<int32_t> n(d), r(d + 1);
+    if (fread(n.data(), sizeof(int32_t), d, f) != (size_t)d || fread(r.data(), sizeof(int32_t), d + 1, f) != (size_t)d + 1) return bad("error reading nr");
+    size_t sz = 0;
+    for (int k = 0; k < d; k++) {
+        if (n[k] < 1 || r[k] < 1 || r[k + 1] < 1 || n[k] > 32000 || r[k] > 128 || r[k + 1] > 128) return bad("tt structure has invalid size");
+        sz += (size_t)r[k] * n[k] * r[k + 1];
+    }
+    std::vector<double> x(sz);
+    if (fread(x.data(), sizeof(double), sz, f) != sz) return bad("error reading cores");
+    fclose(f);
+    // the device engine numbers cores 1..d; a file with l > 1 keeps its shape but loses the offset (every driver has l = 1)
+    return ttx_from_tt(out, d, n.data(), r.data(), x.data(), device);
 }
 
 extern "C" int ttx_quad(ttx_engine *h, const double *w, double *val)
@@ -796,6 +909,7 @@ extern "C" int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efr
     if (!h || !einf || !efro || !ainf || !afro || !h->ran) return fail(TTX_ESTATE, "ttx_accchk: run first");
     if (h->W > 1) return fail(TTX_EINVAL, "dtt_accchk: every rank needs all cores; single-process engines only");
     if (nlot < 1) return fail(TTX_EINVAL, "dtt_accchk: nlot must be positive");
+    if (h->cfg.fun_id == 0) return fail(TTX_ESTATE, "dtt_accchk: this engine holds a loaded tensor train and has no integrand");
     HIPCHECK(hipSetDevice(h->cfg.device));
     switch (h->cfg.fun_id) {
         case TTX_FUN_ISING: return accchk_impl<FUN_ISING>(h, nlot, einf, efro, ainf, afro, pivot);

@@ -89,6 +89,10 @@ def load_library():
     L.ttx_ijk.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_double)]
     L.ttx_zquad.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
     L.ttx_accchk.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int32)]
+    L.ttx_from_tt.argtypes = [POINTER(c_void_p), c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_double), c_int32]
+    L.ttx_write.argtypes = [c_void_p, ctypes.c_char_p]
+    L.ttx_read.argtypes = [POINTER(c_void_p), ctypes.c_char_p, c_int32]
+    L.ttx_get_modes.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32)]
     L.ttx_kernel_stats.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
     L.ttx_k_residual_argmax.argtypes = [c_int32, c_int32, c_int32, POINTER(c_double), POINTER(c_double),
                                         POINTER(c_double), POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
@@ -196,6 +200,42 @@ class TTCross:
         c.use_graph = 1 if use_graph else 0
         self._h = c_void_p()
         _check(L.ttx_create(ctypes.byref(self._h), ctypes.byref(c)))
+
+    # ---- trains that do not come from a sweep (lib/ttio.f90) -----------------------------------
+    @classmethod
+    def _adopt(cls, handle):
+        L = load_library()
+        self = cls.__new__(cls)
+        self._h = handle
+        d = c_int32()
+        _check(L.ttx_get_modes(handle, ctypes.byref(d), None))
+        self.d = d.value
+        self._n = np.zeros(self.d, dtype=np.int32)
+        _check(L.ttx_get_modes(handle, ctypes.byref(d), _ip(self._n)))
+        self.world_rank, self.world_size = 0, 1
+        return self
+
+    @classmethod
+    def from_cores(cls, cores, device=0):
+        """Upload a train given as (r(k-1), n(k), r(k)) arrays; it becomes the resident train of a new engine."""
+        cores = [np.asarray(c, dtype=np.float64) for c in cores]
+        n = np.array([c.shape[1] for c in cores], dtype=np.int32)
+        r = np.array([cores[0].shape[0]] + [c.shape[2] for c in cores], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([c.ravel(order="F") for c in cores]))
+        h = c_void_p()
+        _check(load_library().ttx_from_tt(ctypes.byref(h), len(cores), _ip(n), _ip(r), _dp(flat), int(device)))
+        return cls._adopt(h)
+
+    @classmethod
+    def read(cls, path, device=0):
+        """dtt_read (lib/ttio.f90:196-297): load the reference's stream file onto the device."""
+        h = c_void_p()
+        _check(load_library().ttx_read(ctypes.byref(h), os.fsencode(path), int(device)))
+        return cls._adopt(h)
+
+    def write(self, path):
+        """dtt_write (lib/ttio.f90:29-108): the resident train in the reference's stream format."""
+        _check(load_library().ttx_write(self._h, os.fsencode(path)))
 
     def close(self):
         if getattr(self, "_h", None):

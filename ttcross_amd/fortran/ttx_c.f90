@@ -73,8 +73,33 @@ module ttx_c
    import; type(c_ptr),value :: h; integer(c_int32_t),value :: nlot; real(c_double),intent(out) :: einf,efro,ainf,afro
    integer(c_int32_t),intent(out) :: pivot(*); integer(c_int) :: rc
   end function
+  function ttx_from_tt(h,d,n,r,cores,device) bind(C,name='ttx_from_tt') result(rc)
+   import; type(c_ptr) :: h; integer(c_int32_t),value :: d,device; integer(c_int32_t) :: n(*),r(*); real(c_double) :: cores(*); integer(c_int) :: rc
+  end function
+  function ttx_write(h,path) bind(C,name='ttx_write') result(rc)
+   import; type(c_ptr),value :: h; character(kind=c_char) :: path(*); integer(c_int) :: rc
+  end function
+  function ttx_read(h,path,device) bind(C,name='ttx_read') result(rc)
+   import; type(c_ptr) :: h; character(kind=c_char) :: path(*); integer(c_int32_t),value :: device; integer(c_int) :: rc
+  end function
+  function ttx_get_modes(h,d,n) bind(C,name='ttx_get_modes') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int32_t) :: d; integer(c_int32_t) :: n(*); integer(c_int) :: rc
+  end function
  end interface
 contains
+ subroutine ttx_warn(who)
+  ! print the engine's last error without stopping (the reference's I/O routines report and return, lib/ttio.f90:85-108)
+  character(len=*),intent(in) :: who
+  character(kind=c_char),pointer :: s(:)
+  integer :: i
+  call c_f_pointer(ttx_last_error(),s,[512])
+  write(*,'(a,a)',advance='no') who,': '
+  do i=1,512
+   if(s(i).eq.c_null_char)exit
+   write(*,'(a)',advance='no') s(i)
+  end do
+  write(*,*)
+ end subroutine
  subroutine ttx_check(rc,who)
   ! the reference reports errors as `write(*,*) ...; stop` (e.g. lib/dmrgg.f90:88-91,105-117)
   integer(c_int),intent(in) :: rc
