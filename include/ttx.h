@@ -174,6 +174,10 @@ int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, cons
 int ttx_k_lottery(int32_t device, int32_t npnt, int32_t m, int32_t n, int32_t nz, const int32_t *zcol,
                   const int32_t *zrow, uint64_t rngpos, int32_t *points /* [2*npnt] */);
 
+/* placement probe: the XCD (XCC_ID hardware register) on which each of `nblocks` workgroups of a plain 1-D launch
+ * ran; the cluster sweep kernel relies on workgroups being dealt round-robin to the 8 XCDs */
+int ttx_k_xcc_map(int32_t device, int32_t nblocks, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

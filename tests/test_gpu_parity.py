@@ -284,11 +284,12 @@ def test_zquad_complex_weights():
         assert abs(got[k] - want) <= 1e-12 * abs(want)
 
 
-@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("fused", ["chain", "fused", "cluster"])
 @pytest.mark.parametrize("kind,m,n,r,piv,nproc", [("c", 16, 51, 32, 2, 1), ("c", 64, 51, 32, 2, 8), ("c", 8, 25, 12, 3, 2), ("c", 5, 17, 8, 0, 1)])
 def test_both_sweep_paths_bit_exact(monkeypatch, fused, kind, m, n, r, piv, nproc):
-    """The multi-kernel sweep (TTX_FUSED=0) and the whole-sweep fused kernel (TTX_FUSED=1) against the oracle."""
-    monkeypatch.setenv("TTX_FUSED", fused)
+    """The three sweep implementations -- multi-kernel chain, one workgroup per group (ttx_fused.h), a cluster of
+    workgroups per group (ttx_cluster.h) -- selected with TTX_SWEEP, each bit for bit against the oracle."""
+    monkeypatch.setenv("TTX_SWEEP", fused)
     s = D.ising_setup(kind, m, n)
     tt, oo = _run_both(s, r, piv, nproc=nproc)
     assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d])

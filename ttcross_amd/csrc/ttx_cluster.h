@@ -1,0 +1,452 @@
+// ttx_cluster.h -- the whole sweep of one bond group in ONE launch by a CLUSTER of workgroups (Ising C fast path).
+//
+// The multi-kernel path pays six dependent launches per bond step and the single-workgroup kernel (ttx_fused.h)
+// pushes every fiber through one CU.  Here NB workgroups of 256 threads share a bond group and stay resident for
+// the whole sweep (lib/dmrgg.f90:329-760):
+//   * the blocks of a group are placed on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, so block ids
+//     g, g+8, g+16, ... share an L2): their barrier counter and the factor slabs they exchange stay in that L2;
+//   * each block owns a slice of the mode index (j of the column fiber, k of the row fiber): it evaluates, keeps
+//     (LDS) and later appends exactly that slice, so fibers never travel between blocks;
+//   * the small serial parts (lottery draw and its arg-max, acceptance test) are computed redundantly and
+//     identically by every block, so the only cross-block traffic per rook half-step is one 32-byte partial
+//     arg-max record per block and one cluster barrier;
+//   * the barrier is a monotonic counter in global memory (agent-scope release/acquire).  Every spin is bounded:
+//     a block that waits too long raises the abort flag, all blocks leave, and the host reports the failure.
+// All blocks of all groups must be resident at once: the host only takes this path when G*NB <= number of CUs.
+// Arithmetic and its order are identical to the other two paths (and to the oracle): same device functions, the
+// first-max rule is applied on global fiber positions.
+#pragma once
+#include "ttx_fused.h"
+
+#define CB 256      // threads of a cluster workgroup
+
+// 16-byte records exchanged between the blocks of a cluster: one store / one load instruction each, agent scope
+// (sc1: the store goes through to the point of coherence, the load does not hit in the vector L1)
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+struct ClRec { u4 a, b; };
+static_assert(sizeof(ClRec) == sizeof(ClPart), "record buffers are sized as ClPart");
+__device__ __forceinline__ void st16(void *p, u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u4 ld16(const void *p)
+{
+    u4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// XCC_ID hardware register (id 20, 4 bits): the XCD this wave runs on
+__device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 15; }
+__global__ void k_xcc_probe(int *out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
+
+// barrier across the workgroups of one cluster; false: timed out / aborted (every thread gets the same answer).
+// mode 0: agent-scope release/acquire fences by every wave; mode 1: by one wave (cache maintenance acts on the CU's
+// L1 and the XCD's L2, not on a wave); mode 2: the cluster shares one XCD, so only the L1 is bypassed: stores are
+// complete in the common L2 after the workgroup-scope release, the counter is an L2 atomic, and the vector L1 is
+// invalidated before the block reads its partners' data.
+__device__ __forceinline__ bool cluster_sync(unsigned *ctr, unsigned target, int *abortflag, int *s_ok, int mode)
+{
+    if (mode == 0) __threadfence();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are acknowledged by the L2
+    __syncthreads();                         // ... and so are those of every other wave of the block
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        unsigned spins = 0;
+        if (mode == 2) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            auto peek = [&]() { unsigned v; asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ctr) : "memory"); return v; };
+            while (peek() < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) { ok = 0; __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+            asm volatile("buffer_inv sc0" ::: "memory");
+        } else {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) { ok = 0; __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);   // agent/system scope: drop stale L1/L2 lines
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    if (mode == 0) __threadfence();
+    else if (mode == 2) asm volatile("buffer_inv sc0" ::: "memory");
+    return *s_ok != 0;
+}
+
+#ifdef TTX_STAMPS
+#define CST_DECL const bool t_me = (threadIdx.x == 0 && g == 0 && cb == 0); long long t_prev = wall_clock64()
+#define CST(k) do { if (t_me) { long long t_now = wall_clock64(); gs.stamp[0][k] += t_now - t_prev; t_prev = t_now; } } while (0)
+#define CST_END() do { if (t_me) gs.nstamp[0]++; } while (0)
+#else
+#define CST_DECL
+#define CST(k)
+#define CST_END()
+#endif
+
+__global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int nsteps, int NB, int smode, int ldsinv, int epoch)
+{
+    extern __shared__ __align__(16) double dyn[];
+    __shared__ int zc[128], zr[128], zcs[128], zrs[128], keepc[128], keepr[128];
+    __shared__ int nzc, nzr, nsc, nsr, s_ok;
+    __shared__ ttx_cdfseg segc[TTX_TABSEG], segr[TTX_TABSEG];
+    __shared__ double sha[8], shv[8], shm[8]; __shared__ int shi[8];
+    __shared__ unsigned long long sA[2];
+    const int bid = blockIdx.x;
+    const int g = (bid & 7) + 8 * (bid / (8 * NB)), cb = (bid >> 3) % NB;     // cluster of group g lives on XCD g % 8
+    if (g >= P.G || P.ctl[0]) return;
+    const int tid = threadIdx.x, m = P.d, RM = P.RM, NM = P.NM;
+    const int lane = tid & 63, wv = tid >> 6;
+    GroupState &gs = P.gs[g];
+    const int first = gs.first, last = gs.last, nbonds = last - first + 1;
+    int *r = P.r + (size_t)g * (m + 2);
+    const int VS = ((m + 7) & ~7) + 8;
+    const int n1m = P.n[1];
+    const int SL = RM * ((NM + NB - 1) / NB + 1);       // most fiber entries one block owns
+    unsigned *ctr = P.cl_ctr + g;
+    // the barrier counter and the record tags are never reset: launch number `epoch` (1, 2, ...) of a run starts from
+    // where launch epoch-1 stopped (every launch passes exactly one counter barrier per own bond)
+    unsigned nbar = (unsigned)(epoch - 1) * (unsigned)min(nsteps, nbonds);
+    ClPart *part = P.cl_part;
+    // LDS carve-up
+    double *par = dyn;
+    double *XL = par + ((P.npar + 1) & ~1);            // RM rows x (VS node values, VS weight values)
+    double *XR = XL + (size_t)RM * 2 * VS;
+    double *acol = XR + (size_t)RM * 2 * VS;           // own slice of the column fiber
+    double *arow = acol + SL;                          // own slice of the row fiber
+    double *resc = arow + SL;                          // residuals of the own column / row slice at the last half-step
+    double *resr = resc + SL;                          // that computed them (reused by the append, roles A and B)
+    double *xs = resr + SL;                            // RM
+    int *lot = (int *)(xs + ((RM + 1) & ~1));          // 4 * nlotmax
+    double *GL = (double *)(lot + 4 * ((2 * RM + 2 * NM + 4 + 1) & ~1));   // packed LU of bonds p-1 and p+1 (ldsinv only)
+    double *GU = GL + (size_t)RM * RM;
+    for (int x = tid; x < P.npar; x += CB) par[x] = P.par[x];
+    if (cb == 0 && tid == 0) {                         // sweep start, :325-327
+        int *rr = P.rr + (size_t)g * (m + 2);
+        for (int s = 0; s <= m; s++) rr[s] = r[s];
+    }
+    __syncthreads();
+    double amax = gs.amax, pivotmax = -1.0, pivotmin = -1.0;
+    const double pivotmax_prev = gs.pivotmax_prev;
+    long long neval = gs.neval;
+    unsigned long long rngpos = gs.rngpos;
+    double bytes_half = gs.bytes_half; long long n_resid = gs.n_resid;
+    int hcount = 0;                                    // half-steps exchanged so far (selects the record buffer)
+    const unsigned long long bil0 = ttx_minstd_pow(2ull * tid);     // RNG jump of this thread's first lottery candidate
+    CST_DECL;
+
+    for (int pp = 1; pp <= nsteps; pp++) {
+        if (pp > nbonds) break;
+        const int p = (dir == 1) ? first + pp - 1 : last + 1 - pp;          // :330-331
+        const int r0 = r[p - 1], r1 = r[p], r2 = r[p + 1], n1 = P.n[p], n2 = P.n[p + 1];
+        const int nlot = r0 + n1 + n2 + r2;
+        const int jlo = (int)((long long)cb * n1 / NB), jhi = (int)((long long)(cb + 1) * n1 / NB);   // own columns j of acol1
+        const int klo = (int)((long long)cb * n2 / NB), khi = (int)((long long)(cb + 1) * n2 / NB);   // own rows k of arow1
+        const int nj = jhi - jlo, nk = khi - klo;
+        double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+        double *Ap = core_ptr(P, P.arg, g, p, first), *Aq = core_ptr(P, P.arg, g, p + 1, first);
+        const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+        // ---- stage the value tables of both pivot sets ----
+        for (int x = tid; x < r0 * VS; x += CB) {
+            const int c = x / VS, o = x - c * VS;
+            const int ix = (o < p - 1) ? (int)Lt[(size_t)o * RM + c] : 1;
+            XL[(size_t)c * 2 * VS + o] = par[ix - 1]; XL[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
+        }
+        for (int x = tid; x < r2 * VS; x += CB) {
+            const int c = x / VS, o = x - c * VS;
+            const int ix = (o < m - p - 1) ? (int)Rt[(size_t)o * RM + c] : 1;
+            XR[(size_t)c * 2 * VS + o] = par[ix - 1]; XR[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
+        }
+        if (ldsinv) {                                  // neighbour LU factors for the fix-ups of the append (roles C, D)
+            if (p > first) { const double *gL = inv_ptr(P, g, p - 1, first); for (int x = tid; x < r0 * r0; x += CB) GL[x] = gL[x]; }
+            if (p < last)  { const double *gU = inv_ptr(P, g, p + 1, first); for (int x = tid; x < r2 * r2; x += CB) GU[x] = gU[x]; }
+        }
+        CST(0);
+        // ---- lottery (:410-484): every block draws and scores all candidates (identical results, no traffic) ----
+        if (tid == 32) sA[0] = ttx_minstd_pow(2 * rngpos + 1);
+        if (tid == 33) sA[1] = ttx_minstd_pow(2 * (rngpos + nlot) + 1);
+        const int *vp = vip_ptr(P, g, p, first);
+        if (tid < r1) {
+            zc[tid] = (vp[4 * tid + 0] - 1) + r0 * (vp[4 * tid + 1] - 1) + 1;
+            zr[tid] = (vp[4 * tid + 2] - 1) + n2 * (vp[4 * tid + 3] - 1) + 1;
+        }
+        __syncthreads();
+        if (tid < r1) {
+            int a = zc[tid], b = zr[tid], ra = 0, rb = 0;
+            for (int u = 0; u < r1; u++) { ra += (zc[u] < a) || (zc[u] == a && u < tid); rb += (zr[u] < b) || (zr[u] == b && u < tid); }
+            zcs[ra] = a; zrs[rb] = b;
+        }
+        __syncthreads();
+        if (tid < r1) { keepc[tid] = (tid == 0) || (zcs[tid] != zcs[tid - 1]); keepr[tid] = (tid == 0) || (zrs[tid] != zrs[tid - 1]); }
+        __syncthreads();
+        if (tid < r1) {
+            int pc = 0, pr = 0;
+            for (int u = 0; u < tid; u++) { pc += keepc[u]; pr += keepr[u]; }
+            if (keepc[tid]) zc[pc] = zcs[tid];
+            if (keepr[tid]) zr[pr] = zrs[tid];
+            if (tid == r1 - 1) { nzc = pc + keepc[tid]; nzr = pr + keepr[tid]; }
+        }
+        __syncthreads();
+        const int Kc = r0 * n1 - nzc, Kr = n2 * r2 - nzr;
+        if (tid < 64) { if (tid < P.cdf_ns[Kc]) segc[tid] = P.cdf_tab[(size_t)Kc * TTX_TABSEG + tid]; if (tid == 0) nsc = P.cdf_ns[Kc]; }
+        else if (tid < 128) { const int t2 = tid - 64; if (t2 < P.cdf_ns[Kr]) segr[t2] = P.cdf_tab[(size_t)Kr * TTX_TABSEG + t2]; if (t2 == 0) nsr = P.cdf_ns[Kr]; }
+        __syncthreads();
+        CST(1);
+        double ma = 0.0, ba = -1.0, bv = 0.0; int bi = INT_MAX;
+        for (int il = tid; il < nlot; il += CB) {
+            const unsigned long long bil = (il == tid) ? bil0 : ttx_minstd_pow(2ull * il);
+            const double d1 = ttx_flang_from_word(ttx_mulmod31(sA[0], bil)), d2 = ttx_flang_from_word(ttx_mulmod31(sA[1], bil));
+            const int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);
+            const int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
+            const int i = (x - 1) % r0 + 1, j = (x - 1) / r0 + 1, k = (y - 1) % n2 + 1, q = (y - 1) / n2 + 1;
+            lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
+            const double *rl = XL + (size_t)(i - 1) * 2 * VS, *rq = XR + (size_t)(q - 1) * 2 * VS;
+            const double f = f_ising_c4v(m, p - 1, rl, rl + VS, par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], rq, rq + VS);
+            ma = fmax(ma, fabs(f));
+            const double *c = Cp + (i - 1) + (size_t)RM * (j - 1), *w = Wq + (k - 1) + (size_t)NM * (q - 1);
+            double t = 0.0;
+#pragma unroll 8
+            for (int s = 0; s < r1; s++) t = t + c[P.SS * s] * w[P.SW * s];
+            const double b = f - t, aa = fabs(b);
+            if (aa > ba || (aa == ba && il < bi)) { ba = aa; bv = b; bi = il; }
+        }
+        ma = block_max(ma, sha);
+        amax = fmax(amax, ma);
+        fused_argmax(ba, bv, bi, sha, shv, shi);
+        neval += nlot; rngpos += 2ull * nlot;
+        int ii = lot[4 * bi], jj = lot[4 * bi + 1], kk = lot[4 * bi + 2], qq = lot[4 * bi + 3];
+        double pivot = bv;
+        CST(2);
+        // ---- rook half-steps (:516-582) / piv = 0 (:492-513): own slice, then one record per block ----
+        int havecol = 0, haverow = 0, crs = 0, done = 0;
+        int rc_k = -1, rc_q = -1, rr_i = -1, rr_j = -1;     // pivot at which resc / resr were computed (-1: not valid)
+        const int H = (P.piv == 0) ? 2 : 2 * P.piv;
+        for (int h = 0; h < H && !done; h++) {
+            const bool iscol = (P.piv == 0) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);
+            const int nf = iscol ? r0 * n1 : n2 * r2;
+            const int nsl = iscol ? r0 * nj : nk * r2;
+            double *fib = iscol ? acol : arow;
+            if (iscol) for (int s = tid; s < r1; s += CB) xs[s] = Wq[(kk - 1) + (size_t)NM * (qq - 1) + P.SW * s];
+            else       for (int s = tid; s < r1; s += CB) xs[s] = Cp[(ii - 1) + (size_t)RM * (jj - 1) + P.SS * s];
+            crs++;
+            if (iscol) havecol = 1; else haverow = 1;
+            const int dn = (P.piv == 0) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));
+            const bool resid = (P.piv != 0) && !dn;
+            if (iscol) { rc_k = resid ? kk : -1; rc_q = qq; } else { rr_i = resid ? ii : -1; rr_j = jj; }
+            __syncthreads();
+            CST(3);
+            double mx = 0.0, ab = -1.0, bb = 0.0; int ix = INT_MAX;
+            for (int u = tid; u < nsl; u += CB) {
+                double a;
+                if (iscol) {
+                    const int i = u % r0, j = jlo + u / r0, t = i + r0 * j;
+                    const double *rl = XL + (size_t)i * 2 * VS, *rq = XR + (size_t)(qq - 1) * 2 * VS;
+                    const double *c = Cp + i + (size_t)RM * j;
+                    a = f_ising_c4v(m, p - 1, rl, rl + VS, par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], rq, rq + VS);
+                    fib[u] = a;
+                    if (resid) {
+                        double b = a;
+#pragma unroll 8
+                        for (int s = 0; s < r1; s++) b = b + (-xs[s]) * c[P.SS * s];
+                        resc[u] = b;
+                        const double aa = fabs(b);
+                        if (aa > ab || (aa == ab && t < ix)) { ab = aa; bb = b; ix = t; }
+                    }
+                } else {
+                    const int k = klo + u % nk, q = u / nk, t = k + n2 * q;
+                    const double *rl = XL + (size_t)(ii - 1) * 2 * VS, *rq = XR + (size_t)q * 2 * VS;
+                    const double *w = Wq + k + (size_t)NM * q;
+                    a = f_ising_c4v(m, p - 1, rl, rl + VS, par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], rq, rq + VS);
+                    fib[u] = a;
+                    if (resid) {
+                        double tt = 0.0;
+#pragma unroll 8
+                        for (int s = 0; s < r1; s++) tt = tt + w[P.SW * s] * xs[s];
+                        const double b = a + (-1.0) * tt;
+                        resr[u] = b;
+                        const double aa = fabs(b);
+                        if (aa > ab || (aa == ab && t < ix)) { ab = aa; bb = b; ix = t; }
+                    }
+                }
+                mx = fmax(mx, fabs(a));
+            }
+            CST(4);
+            mx = wave_max(mx);
+            wave_argmax(ab, bb, ix);
+            if (lane == 0) { shm[wv] = mx; sha[wv] = ab; shv[wv] = bb; shi[wv] = ix; }
+            __syncthreads();
+            // exchange: every block publishes one tagged 32-byte record {|b|max, position, sign, tag}{fiber max, tag};
+            // wave 0 polls the NB records of this half-step (L1-bypassing 16-byte loads) and reduces them.  No fence:
+            // nothing but the records crosses blocks here (fibers stay in LDS, factors were published at the end of
+            // earlier bond steps).  Records are double-buffered by half-step parity; the tag carries the launch number.
+            ClRec *buf = (ClRec *)part + ((size_t)(hcount & 1) * P.G + g) * TTX_CLMAX;
+            const unsigned gen = ((unsigned)epoch << 20) | (unsigned)(hcount + 1);
+            if (wv == 0) {
+                if (lane == 0) {
+                    for (int x = 1; x < CB / 64; x++) {
+                        mx = fmax(mx, shm[x]);
+                        if (sha[x] > ab || (sha[x] == ab && shi[x] < ix)) { ab = sha[x]; bb = shv[x]; ix = shi[x]; }
+                    }
+                    const unsigned long long ua = (unsigned long long)__double_as_longlong(ab), um = (unsigned long long)__double_as_longlong(mx);
+                    u4 ra, rb;
+                    ra.x = (unsigned)ua; ra.y = (unsigned)(ua >> 32); ra.z = (unsigned)ix; ra.w = gen | (signbit(bb) ? 0x80000000u : 0u);
+                    rb.x = (unsigned)um; rb.y = (unsigned)(um >> 32); rb.z = gen; rb.w = 0;
+                    st16(&buf[cb].a, ra); st16(&buf[cb].b, rb);
+                }
+                CST(5);
+                int ok = 1;
+                mx = 0.0; ab = -1.0; bb = 0.0; ix = INT_MAX;
+                if (lane < NB) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        const u4 ra = ld16(&buf[lane].a), rb = ld16(&buf[lane].b);
+                        if ((ra.w & 0x7fffffffu) == gen && rb.z == gen) {
+                            ab = __longlong_as_double((long long)(((unsigned long long)ra.y << 32) | ra.x));
+                            mx = __longlong_as_double((long long)(((unsigned long long)rb.y << 32) | rb.x));
+                            ix = (int)ra.z;
+                            bb = (ra.w & 0x80000000u) ? -ab : ab;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) { ok = 0; break; }
+                        if ((spins & 1023u) == 0 && __hip_atomic_load(P.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { ok = 0; break; }
+                    }
+                }
+                ok = __all(ok);
+                mx = wave_max(mx);
+                wave_argmax(ab, bb, ix);
+                if (lane == 0) {
+                    if (!ok) __hip_atomic_store(P.cl_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    s_ok = ok; shm[0] = mx; sha[0] = ab; shv[0] = bb; shi[0] = ix;
+                }
+            }
+            __syncthreads();
+            if (!s_ok) return;
+            CST(6);
+            mx = shm[0]; ab = sha[0]; bb = shv[0]; ix = shi[0];
+            hcount++;
+            amax = fmax(amax, mx);
+            neval += nf;
+            bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
+            n_resid += resid ? 1 : 0;
+            done = dn;
+            if (resid) {
+                if (iscol) { const int i = ix % r0 + 1, j = ix / r0 + 1; done = havecol && haverow && (i == ii && j == jj); ii = i; jj = j; }
+                else       { const int k = ix % n2 + 1, q = ix / n2 + 1; done = havecol && haverow && (k == kk && q == qq); kk = k; qq = q; }
+                pivot = bb;
+            }
+        }
+        __syncthreads();
+        CST(7);
+        // ---- acceptance and in-place append (:598-758): every block appends its own slice ----
+        int *tape = P.tape + ((size_t)g * (m + 2) + p) * 4;
+        const bool upd = (fabs(pivot) > P.small_element * amax) && (fabs(pivot) > P.small_pivot * pivotmax_prev);
+        if (!upd) {
+            if (cb == 0 && tid == 0) { tape[0] = tape[1] = tape[2] = tape[3] = -1; P.upd[(size_t)g * (m + 2) + p] = 0; }
+        } else {
+            const int i0 = ii - 1, j0 = jj - 1, k0 = kk - 1, q0 = qq - 1;
+            double *gI = inv_ptr(P, g, p, first);
+            // role E first part: packed LU from the OLD factors (:649-660)
+            if (cb == 0)
+                for (int s = tid; s < r1; s += CB) {
+                    gI[r1 * r1 + s] = Cp[i0 + (size_t)RM * j0 + P.SS * s];
+                    gI[r1 * r1 + r1 + s] = Wq[k0 + (size_t)NM * q0 + P.SW * s];
+                }
+            // role A: arg(p), col(p) new slab (:662-668, :701)
+            for (int s = tid; s < r1; s += CB) xs[s] = Wq[k0 + (size_t)NM * q0 + P.SW * s];
+            __syncthreads();
+            const bool reuseA = (rc_k == kk && rc_q == qq), reuseB = (rr_i == ii && rr_j == jj);
+            for (int u = tid; u < r0 * nj; u += CB) {
+                const int i = u % r0, j = jlo + u / r0; const size_t o = i + (size_t)RM * j;
+                const double a = acol[u];
+                Ap[o + P.SS * r1] = a;
+                double y;
+                if (reuseA) y = resc[u];             // the same sum, in the same order, as the last column half-step
+                else {
+                    y = a;
+#pragma unroll 16
+                    for (int s = 0; s < r1; s++) y = y + (-xs[s]) * Cp[o + P.SS * s];
+                }
+                Cp[o + P.SS * r1] = (1.0 / pivot) * y;
+            }
+            __syncthreads();
+            // role B: arg(p+1), row(p+1) new row (:669-674, :702)
+            for (int s = tid; s < r1; s += CB) xs[s] = Cp[i0 + (size_t)RM * j0 + P.SS * s];
+            __syncthreads();
+            for (int u = tid; u < nk * r2; u += CB) {
+                const int k = klo + u % nk, q = u / nk;
+                const double a = arow[u];
+                Aq[r1 + (size_t)RM * k + P.SS * q] = a;
+                const size_t o = k + (size_t)NM * q;
+                if (reuseB) Wq[o + P.SW * r1] = resr[u];
+                else {
+                    double tt = 0.0;
+#pragma unroll 16
+                    for (int s = 0; s < r1; s++) tt = tt + Wq[o + P.SW * s] * xs[s];
+                    Wq[o + P.SW * r1] = a + (-1.0) * tt;
+                }
+            }
+            CST(8);
+            // role C: row(p)(:, j, r1+1) = L(p-1)^-1 acol1(:, j)  (:715-728): one wave per own column
+            if (p > first) {
+                const double *gL = ldsinv ? GL : inv_ptr(P, g, p - 1, first);
+                double *Wp = core_ptr(P, P.row, g, p, first);
+                for (int jl = wv; jl < nj; jl += CB / 64) {
+                    const int j = jlo + jl;
+                    const double a = (lane < r0) ? acol[lane + r0 * jl] : 0.0;
+                    double tmp = 0.0, xf = 0.0;
+                    for (int s = 0; s < r0; s++) {
+                        const double cand = (s == 0) ? a : a + (-1.0) * tmp;
+                        const double xsv = __shfl(cand, s, 64);
+                        if (lane == s) xf = xsv;
+                        if (lane > s && lane < r0) tmp = tmp + xsv * gL[lane * lane + s];
+                    }
+                    if (lane < r0) Wp[j + (size_t)NM * r1 + P.SW * lane] = xf;
+                }
+            }
+            // role D: col(p+1)(r1+1, k, :) = arow1(k, :) U(p+1)^-1  (:730-749): one wave per own row
+            if (p < last) {
+                const double *gU = ldsinv ? GU : inv_ptr(P, g, p + 1, first);
+                double *Cq = core_ptr(P, P.col, g, p + 1, first);
+                for (int kl = wv; kl < nk; kl += CB / 64) {
+                    const int k = klo + kl;
+                    double y = (lane < r2) ? arow[kl + nk * lane] : 0.0;
+                    for (int s = 0; s < r2; s++) {
+                        const double dg = gU[(s + 1) * (s + 1) - 1];
+                        const double cand = (1.0 / dg) * y;
+                        const double ys = __shfl(cand, s, 64);
+                        if (lane == s) y = ys;
+                        if (lane > s && lane < r2) y = y + (-gU[lane * lane + lane + s]) * ys;
+                    }
+                    if (lane < r2) Cq[r1 + (size_t)RM * k + P.SS * lane] = y;
+                }
+            }
+            // role E: index tables, pivot set, scalars (:604-635)
+            if (cb == 0) {
+                short *Ln = L_ptr(P, g, p, first), *Rn = R_ptr(P, g, p, first);
+                for (int x = tid; x < p; x += CB) Ln[(size_t)x * RM + r1] = (x < p - 1) ? Lt[(size_t)x * RM + i0] : (short)(j0 + 1);
+                for (int x = tid; x < m - p; x += CB) Rn[(size_t)x * RM + r1] = (x == 0) ? (short)(k0 + 1) : Rt[(size_t)(x - 1) * RM + q0];
+                if (tid == 0) {
+                    gI[(r1 + 1) * (r1 + 1) - 1] = pivot;
+                    int *vq = vip_ptr(P, g, p, first) + 4 * r1;
+                    vq[0] = tape[0] = ii; vq[1] = tape[1] = jj; vq[2] = tape[2] = kk; vq[3] = tape[3] = qq;
+                    P.upd[(size_t)g * (m + 2) + p] = 1;
+                    r[p] = r1 + 1;                                                      // :752
+                }
+            }
+            const double ap = fabs(pivot);
+            pivotmax = (pivotmax < 0.0) ? ap : fmax(pivotmax, ap);
+            pivotmin = (pivotmin < 0.0) ? ap : fmin(pivotmin, ap);
+        }
+        CST(9);
+        // end of the bond step: appends and the new rank become visible to the whole cluster (every block read r[] of
+        // this step before its first half-step barrier, so block 0 may already have overwritten r[p])
+        if (!cluster_sync(ctr, (++nbar) * (unsigned)NB, P.cl_abort, &s_ok, smode)) return;
+        CST(10);
+        CST_END();
+    }
+    if (cb == 0 && tid == 0) {
+        gs.amax = amax; gs.pivotmax = pivotmax; gs.pivotmin = pivotmin; gs.neval = neval; gs.rngpos = rngpos;
+        gs.bytes_half = bytes_half; gs.n_resid = n_resid;
+    }
+}

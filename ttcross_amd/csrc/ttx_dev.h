@@ -68,6 +68,9 @@ struct GroupState {
     Partial Pt[2][TTX_MAXPART];
 };
 
+#define TTX_CLMAX 16            // most workgroups one bond group's cluster may have
+struct ClPart { double ab, bb, mx; int ix, pad; };
+
 struct DevProb {
     int d, RM, NM, G, NC;      // cores, max rank, max mode size, local groups, max cores per group
     int fun_id, piv, npar, ising_id;
@@ -109,4 +112,14 @@ struct DevProb {
     const int *cdf_ns;             // [cdf_kmax+1]
     int cdf_kmax;
     GroupState *gs;            // [G]
+    // device-side stopping rule (lib/dmrgg.f90:1011-1019) so that the host can enqueue the next sweep before it has
+    // read the summary of the current one: ctl[0] stop, ctl[1] strike counter, ctl[2] stop as seen when the
+    // quadrature of the sweep was forked to its own stream
+    int *ctl;
+    int *rq;                       // [G][d+2] ranks at the end of the sweep, for the forked quadrature
+    double accuracy; int maxrank;
+    // cluster sweep kernel (ttx_cluster.h): per-group barrier counters, abort flag, per-block partial arg-max records
+    unsigned *cl_ctr;              // [G]
+    int *cl_abort;                 // [1]
+    struct ClPart *cl_part;        // [2][G][TTX_CLMAX]
 };

@@ -23,6 +23,7 @@
 #include "ttx_kernels.h"
 #include "ttx_ttops.h"
 #include "ttx_fused.h"
+#include "ttx_cluster.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const char *fmt, ...)
@@ -109,6 +110,14 @@ struct ttx_engine {
     int half_vals = 0;
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
+    hipStream_t qstream = nullptr;      // forked per-sweep quadrature (single-process runs)
+    hipEvent_t ev_fork = nullptr, ev_sum[2] = {nullptr, nullptr}, ev_val[2] = {nullptr, nullptr};
+    double *h_sum_base = nullptr;       // pinned [2][SB]: summaries of the two sweeps in flight
+    double *h_val = nullptr;            // pinned [2]: per-sweep quadrature values
+    int cluster_ldsinv = 0;             // cluster kernel keeps the neighbour LU factors in LDS
+    int cluster = 0;                    // workgroups per bond group of the cluster sweep kernel (ttx_cluster.h); 0: not used
+    size_t lds_cluster = 0;
+    int *h_abort = nullptr;             // pinned, device-visible: the cluster kernel's barrier-timeout flag
 };
 
 template <class T>
@@ -250,7 +259,18 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         HIPCHECK(hipMemcpy(P.inR, ir.data(), sizeof(char *) * G, hipMemcpyHostToDevice));
     }
 #undef A_
-    HIPCHECK(hipHostMalloc((void **)&h->h_sum, sizeof(double) * h->SB));
+    {
+        int *ctl, *rq;
+        rc = dev_alloc(h, &ctl, (size_t)4); if (rc) { ttx_destroy(h); return rc; }
+        rc = dev_alloc(h, &rq, (size_t)G * (d + 2)); if (rc) { ttx_destroy(h); return rc; }
+        P.ctl = ctl; P.rq = rq; P.accuracy = cfg->accuracy; P.maxrank = cfg->maxrank;
+    }
+    HIPCHECK(hipHostMalloc((void **)&h->h_sum_base, sizeof(double) * 2 * h->SB));
+    h->h_sum = h->h_sum_base;
+    HIPCHECK(hipHostMalloc((void **)&h->h_val, sizeof(double) * 2));
+    HIPCHECK(hipStreamCreateWithFlags(&h->qstream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int x = 0; x < 2; x++) { HIPCHECK(hipEventCreateWithFlags(&h->ev_sum[x], hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_val[x], hipEventDisableTiming)); }
     HIPCHECK(hipHostMalloc((void **)&h->h_msg, 4 * P.MSZ));
     HIPCHECK(hipHostMalloc((void **)&h->h_tmp, sizeof(double) * std::max(h->QB, h->SB)));
     {   // lottery CDF segment tables for every K that can occur (K <= maxrank*n): pure function of K, see ttx_cdf.h
@@ -289,14 +309,39 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         const size_t VS = ((d + 7) & ~7) + 8;
         h->lds_lot = sizeof(double) * (cfg->npar + 4) + sizeof(int) * 4 * (nlotmax + 4) + sizeof(short) * (2 * RM * VS + 16);
     }
-    {   // whole-sweep fused kernel: Ising C, rank <= one wave, everything of a bond step in one CU's LDS
+    {   // whole-sweep kernels (Ising C): TTX_SWEEP = auto | chain | fused | cluster
         const size_t VS = ((d + 7) & ~7) + 8;
         const int nlotmax = 2 * h->RM + 2 * NM;
+        const char *env = getenv("TTX_SWEEP");
+        const std::string want = env ? env : "auto";
+        const bool fastc = cfg->fun_id == TTX_FUN_ISING && P.ising_id == 1 && cfg->pivoting >= 0 && P.cdf_tab != nullptr;
+        // one 1024-thread workgroup per group: everything of a bond step in one CU's LDS
         h->lds_fused = sizeof(double) * (cfg->npar + 4 + 4 * RM * VS + 2 * RM * NM + RM + 4) + sizeof(int) * 4 * (nlotmax + 4);
-        const char *env = getenv("TTX_FUSED");
-        const bool want = env ? atoi(env) != 0 : (h->G == 1);   // measured: wins for one group, loses when 8 groups share a launch
-        h->fused = want && cfg->fun_id == TTX_FUN_ISING && P.ising_id == 1 && cfg->pivoting >= 0 && h->RM <= 64 && nlotmax <= FB &&
-                   P.cdf_tab != nullptr && h->lds_fused <= 150 * 1024;
+        const bool fused_ok = fastc && h->RM <= 64 && nlotmax <= FB && h->lds_fused <= 150 * 1024;
+        // a cluster of NB 256-thread workgroups per group, all resident at once (G*NB <= number of CUs)
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, cfg->device));
+        int NB = 8;
+        if (const char *e = getenv("TTX_CLUSTER_NB")) NB = atoi(e);
+        NB = std::max(1, std::min(NB, TTX_CLMAX));
+        while (NB > 1 && h->G * NB > prop.multiProcessorCount / 2) NB--;        // leave room for other processes on the card
+        const size_t SL = (size_t)RM * ((NM + NB - 1) / NB + 1);
+        h->lds_cluster = sizeof(double) * (cfg->npar + 4 + 4 * RM * VS + 4 * SL + RM + 4) + sizeof(int) * 4 * (nlotmax + 4);
+        if (h->lds_cluster + sizeof(double) * 2 * RM * RM <= 150 * 1024) { h->cluster_ldsinv = 1; h->lds_cluster += sizeof(double) * 2 * RM * RM; }
+        const bool cluster_ok = fastc && h->RM <= 128 && NB >= 2 && h->G * NB <= prop.multiProcessorCount && h->lds_cluster <= 150 * 1024;
+        if (want == "cluster") { if (cluster_ok) h->cluster = NB; }
+        else if (want == "fused") { if (fused_ok) h->fused = 1; }
+        else if (want == "auto") { if (cluster_ok) h->cluster = NB; else if (fused_ok && h->G == 1) h->fused = 1; }
+        else if (want != "chain") { ttx_destroy(h); return fail(TTX_EINVAL, "TTX_SWEEP must be auto, chain, fused or cluster (got %s)", want.c_str()); }
+        if (h->cluster) {
+            unsigned *ctr; ClPart *cp;
+            rc = dev_alloc(h, &ctr, (size_t)h->G); if (rc) { ttx_destroy(h); return rc; }
+            rc = dev_alloc(h, &cp, (size_t)2 * h->G * TTX_CLMAX); if (rc) { ttx_destroy(h); return rc; }
+            P.cl_ctr = ctr; P.cl_part = cp;
+            HIPCHECK(hipHostMalloc((void **)&h->h_abort, sizeof(int)));
+            *h->h_abort = 0;
+            P.cl_abort = h->h_abort;
+        }
     }
     if (h->lds_half > 160 * 1024 || h->lds_lot > 120 * 1024) { ttx_destroy(h); return fail(TTX_EINVAL, "problem too large for LDS staging (d*maxrank)"); }
     *out = h;
@@ -309,9 +354,14 @@ extern "C" void ttx_destroy(ttx_engine *h)
     if (!h) return;
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     for (void *p : h->allocs) (void)hipFree(p);
-    if (h->h_sum) (void)hipHostFree(h->h_sum);
+    if (h->h_sum_base) (void)hipHostFree(h->h_sum_base);
+    if (h->h_val) (void)hipHostFree(h->h_val);
+    if (h->qstream) (void)hipStreamDestroy(h->qstream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int x = 0; x < 2; x++) { if (h->ev_sum[x]) (void)hipEventDestroy(h->ev_sum[x]); if (h->ev_val[x]) (void)hipEventDestroy(h->ev_val[x]); }
     if (h->h_msg) (void)hipHostFree(h->h_msg);
     if (h->h_tmp) (void)hipHostFree(h->h_tmp);
+    if (h->h_abort) (void)hipHostFree(h->h_abort);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -534,6 +584,8 @@ static int run_impl(ttx_engine *h)
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_halfstep<FUN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_half));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lottery<FUN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_lot));
     if (h->fused) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fused));
+    if (h->cluster) *h->h_abort = 0;
+    if (h->cluster) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_cluster));
     // ---- reset state (lib/dmrgg.f90:96-100, 141-148, 279-288) ----
     {
         std::vector<GroupState> gs(G);
@@ -579,14 +631,32 @@ static int run_impl(ttx_engine *h)
     bool ready = (it + 1 >= h->cfg.maxrank);
     const int nfb = (h->RM * h->NM + TTX_BLK - 1) / TTX_BLK;
     const size_t lds_acc = sizeof(double) * (h->RM + 2);
-    while (!ready) {
-        it++;
-        const int dir = 2 - it % 2;
-        if (h->fused) {
+    // Pipelined mode (whole-sweep kernels, device-resident transport): the stopping rule also runs on the device
+    // (k_ctl), so sweep it+1 is enqueued BEFORE the host has read the summary of sweep it -- the GPU never waits for
+    // the host.  When the rule fires, the one sweep that is already enqueued finds the stop flag and does nothing.
+    // On a single GPU the per-sweep quadrature (only reported, never fed back) runs on its own stream next to the
+    // following sweep: it reads a snapshot of the ranks and only slabs that already exist (appends are in place).
+    const bool pipe = (h->cluster || h->fused) && (h->W == 1 || h->comm) && !h->profile;
+    const bool forkq = pipe && h->W == 1 && P.has_quad;
+    HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 4, st));
+    if (h->cluster) {
+        HIPCHECK(hipMemsetAsync(P.cl_ctr, 0, sizeof(unsigned) * G, st));
+        HIPCHECK(hipMemsetAsync(P.cl_part, 0, sizeof(ClPart) * 2 * G * TTX_CLMAX, st));
+    }
+    DevProb Pq = P;
+    if (pipe) Pq.r = P.rq;
+
+    auto enqueue_sweep = [&](int it_) -> int {
+        const int dir = 2 - it_ % 2, slot = it_ & 1;
+        if (h->cluster) {
+            KScope ks(h, TTX_K_HALFSTEP, 1);
+            hipLaunchKernelGGL(k_sweep_cluster, dim3(8 * h->cluster * ((G + 7) / 8)), dim3(CB), h->lds_cluster, st, P, dir, h->nbmax, h->cluster,
+                               getenv("TTX_CLUSTER_SYNC") ? atoi(getenv("TTX_CLUSTER_SYNC")) : 1, h->cluster_ldsinv, it_);
+        } else if (h->fused) {
             KScope ks(h, TTX_K_HALFSTEP, 1);
             hipLaunchKernelGGL(k_sweep_fused, dim3(G), dim3(FB), h->lds_fused, st, P, dir, h->nbmax);
         }
-        for (int pp = 1; pp <= h->nbmax && !h->fused; pp++) {
+        for (int pp = 1; pp <= h->nbmax && !h->fused && !h->cluster; pp++) {
             if (h->cfg.pivoting >= 0) {
                 { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp); }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
@@ -604,28 +674,64 @@ static int run_impl(ttx_engine *h)
             }
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }
+        if (forkq) HIPCHECK(hipStreamWaitEvent(st, h->ev_val[slot ^ 1], 0));   // the previous quadrature is done with the boundaries
         {   // per-sweep exchange between bond groups (:763-961)
             KScope ks(h, TTX_K_EXCHANGE, (h->W > 1 ? 4 : 2) + (nproc > 1 ? 1 : 0));
             hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
             if (h->W > 1) {
                 hipLaunchKernelGGL(k_exch_localmax, dim3(1), dim3(64), 0, st, P);
-                if ((rc = xfer_neighbours(h))) return rc;
-                if ((rc = allreduce_dev(h, P.redsend, P.redrecv, 4, 1))) return rc;
+                if (int rc_ = xfer_neighbours(h)) return rc_;
+                if (int rc_ = allreduce_dev(h, P.redsend, P.redrecv, 4, 1)) return rc_;
             }
             hipLaunchKernelGGL(k_exch_max_apply, dim3(G), dim3(256), 0, st, P, h->W > 1 ? 1 : 0, nproc > 1 ? 1 : 0);
             if (nproc > 1)
                 hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8), st, P);
         }
+        const bool one_end = pipe && h->W == 1;      // snapshot + summary + stopping rule in one launch
+        if (one_end) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_);
+        else if (pipe) hipLaunchKernelGGL(k_fork, dim3(1), dim3(256), 0, st, P);
         if (P.has_quad) {
+            hipStream_t sq = forkq ? h->qstream : st;
+            if (forkq) { HIPCHECK(hipEventRecord(h->ev_fork, st)); HIPCHECK(hipStreamWaitEvent(sq, h->ev_fork, 0)); }
             KScope ks(h, TTX_K_QUAD, nproc > 1 ? 3 : 2);
-            if ((rc = launch_quad(h, 0, P.quadw))) return rc;
+            const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
+            hipLaunchKernelGGL(k_quad_build, dim3(h->NC, G), dim3(256), lds_q, sq, pipe ? Pq : P, 0, P.quadw);
+            hipLaunchKernelGGL(k_quad_chain, dim3(G), dim3(256), 2 * lds_q, sq, pipe ? Pq : P);
+            if (nproc > 1) {
+                if (int rc_ = allreduce_dev(h, P.qsend, P.qall, h->QB, 0)) return rc_;     // W > 1: sq is the main stream
+                hipLaunchKernelGGL(k_quad_tree, dim3(1), dim3(256), 0, sq, pipe ? Pq : P);
+            }
+            if (pipe) {
+                HIPCHECK(hipMemcpyAsync(h->h_val + slot, &P.gs[0].val, sizeof(double), hipMemcpyDeviceToHost, sq));
+                HIPCHECK(hipEventRecord(h->ev_val[slot], sq));
+            }
         }
-        if ((rc = readback(h))) return rc;
+        if (pipe) {
+            if (!one_end) {
+                hipLaunchKernelGGL(k_collect, dim3(1), dim3(64), 0, st, P);
+                if (int rc_ = allreduce_dev(h, P.sumsend, P.sumrecv, h->SB, 0)) return rc_;
+                hipLaunchKernelGGL(k_ctl, dim3(1), dim3(64), 0, st, P, it_);
+            }
+            HIPCHECK(hipMemcpyAsync(h->h_sum_base + (size_t)slot * h->SB, P.sumrecv, sizeof(double) * h->SB, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipEventRecord(h->ev_sum[slot], st));
+        }
+        return TTX_OK;
+    };
+    // host side of a finished sweep: record, tapes, log line, stopping rule (identical to k_ctl)
+    auto process_sweep = [&](int it_) -> int {
+        const int dir = 2 - it_ % 2, slot = it_ & 1;
+        if (pipe) {
+            HIPCHECK(hipEventSynchronize(h->ev_sum[slot]));
+            h->h_sum = h->h_sum_base + (size_t)slot * h->SB;
+            if (P.has_quad) { HIPCHECK(hipEventSynchronize(h->ev_val[slot])); val = h->h_val[slot]; }
+        } else {
+            if (int rc_ = readback(h)) return rc_;
+            if (P.has_quad) val = h->h_sum[SUM_VAL];      // every GPU ran the same tree on the same gathered matrices
+        }
         HIPCHECK(hipGetLastError());
-        // every GPU ran the same tree on the same gathered matrices: val is identical everywhere
-        if (P.has_quad) val = h->h_sum[SUM_VAL];
+        if (h->cluster && *(volatile int *)h->h_abort) return fail(TTX_EHIP, "cluster sweep kernel: barrier timed out (workgroups of a bond group were not co-resident)");
         ttx_sweep_rec r{};
-        r.it = it; r.dir = dir; r.erank = erank_host(h, rank0_view(h, it).data()); r.neval = (int64_t)h->h_sum[SUM_NEVAL]; r.val = val;
+        r.it = it_; r.dir = dir; r.erank = erank_host(h, rank0_view(h, it_).data()); r.neval = (int64_t)h->h_sum[SUM_NEVAL]; r.val = val;
         r.amax = h->h_sum[SUM_AMAX]; r.pivotmax = h->h_sum[SUM_PMAX]; r.pivotmin = h->h_sum[SUM_PMIN]; r.seconds = since();
         h->recs.push_back(r);
         {
@@ -635,11 +741,30 @@ static int run_impl(ttx_engine *h)
         }
         if (h->cfg.verbose) print_line(h, r, val_prev);
         val_prev = val;
-        ready = ready || (it + 1 >= h->cfg.maxrank);                              // :1011
+        ready = ready || (it_ + 1 >= h->cfg.maxrank);                             // :1011
         if (h->cfg.accuracy >= 0.0) {                                             // :1012-1019 (rank 0's amax, global pivotmax)
             if (r.pivotmax <= h->cfg.accuracy * r.amax) strike++; else strike = 0;
             ready = ready || (strike >= 3);
         }
+        return TTX_OK;
+    };
+    if (!pipe) {
+        while (!ready) {
+            it++;
+            if ((rc = enqueue_sweep(it))) return rc;
+            if ((rc = process_sweep(it))) return rc;
+        }
+    } else if (!ready) {
+        if (forkq) { HIPCHECK(hipEventRecord(h->ev_val[0], h->qstream)); HIPCHECK(hipEventRecord(h->ev_val[1], h->qstream)); }
+        if ((rc = enqueue_sweep(1))) return rc;
+        for (it = 1; !ready; it++) {
+            if (it + 1 < h->cfg.maxrank && (rc = enqueue_sweep(it + 1))) return rc;    // a no-op on the device once the rule has fired
+            if ((rc = process_sweep(it))) return rc;
+        }
+        it--;
+        HIPCHECK(hipStreamSynchronize(st));
+        if (forkq) HIPCHECK(hipStreamSynchronize(h->qstream));
+        HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 4, st));
     }
     // ---- finalise (:1029): dtt_lua shifts the rightmost inv of every group to its neighbour first ----
     {
@@ -660,7 +785,7 @@ static int run_impl(ttx_engine *h)
         HIPCHECK(hipMemcpy(&g0s, P.gs, sizeof(GroupState), hipMemcpyDeviceToHost));
         for (int k = 0; k < 2; k++) {
             fprintf(stderr, "stamps kernel %d (n=%lld):", k, g0s.nstamp[k]);
-            for (int x = 0; x < 10; x++) fprintf(stderr, " %.2fus", g0s.nstamp[k] ? 0.01 * (double)g0s.stamp[k][x] / (double)g0s.nstamp[k] : 0.0);
+            for (int x = 0; x < 12; x++) fprintf(stderr, " %.2fus", g0s.nstamp[k] ? 0.01 * (double)g0s.stamp[k][x] / (double)g0s.nstamp[k] : 0.0);
             fprintf(stderr, "\n");
         }
     }
@@ -1262,6 +1387,17 @@ extern "C" int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32
     return TTX_OK;
 }
 
+extern "C" int ttx_k_xcc_map(int32_t device, int32_t nblocks, int32_t *out)
+{
+    if (!out || nblocks < 1) return fail(TTX_EINVAL, "ttx_k_xcc_map: bad argument");
+    HIPCHECK(hipSetDevice(device));
+    int *d = nullptr;
+    HIPCHECK(hipMalloc((void **)&d, sizeof(int) * nblocks));
+    hipLaunchKernelGGL(k_xcc_probe, dim3(nblocks), dim3(256), 0, 0, d);
+    HIPCHECK(hipMemcpy(out, d, sizeof(int) * nblocks, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return TTX_OK;
+}
 extern "C" int ttx_k_lottery(int32_t device, int32_t npnt, int32_t m, int32_t n, int32_t nz, const int32_t *zcol,
                              const int32_t *zrow, uint64_t rngpos, int32_t *points)
 {

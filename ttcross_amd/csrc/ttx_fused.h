@@ -56,6 +56,7 @@ __global__ __launch_bounds__(FB) void k_sweep_fused(DevProb P, int dir, int nste
     __shared__ ttx_cdfseg segc[TTX_TABSEG], segr[TTX_TABSEG];
     __shared__ double sha[16], shv[16]; __shared__ int shi[16];
     __shared__ unsigned long long sA[2];
+    if (P.ctl[0]) return;
     const int g = blockIdx.x, tid = threadIdx.x, m = P.d, RM = P.RM, NM = P.NM;
     const int lane = tid & 63, wv = tid >> 6;
     GroupState &gs = P.gs[g];

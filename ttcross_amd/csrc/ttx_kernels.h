@@ -983,6 +983,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_accept(DevProb P, int H, int nA)
 // mode 1: T = sum_j w_j arg(:,j,:) on finalised cores (w == NULL: plain sum)
 __global__ __launch_bounds__(256) void k_quad_build(DevProb P, int mode, const double *wq)
 {
+    if (P.ctl[2]) return;
     extern __shared__ double T[];   // RM*RM
     const int g = blockIdx.y, tid = threadIdx.x, RM = P.RM;
     GroupState &gs = P.gs[g];
@@ -1030,6 +1031,7 @@ __global__ __launch_bounds__(256) void k_quad_build(DevProb P, int mode, const d
 // chain product of the group's T matrices (dgemm 'n','n' order, :1340); one block per group
 __global__ __launch_bounds__(256) void k_quad_chain(DevProb P)
 {
+    if (P.ctl[2]) return;
     extern __shared__ double sh[];  // 2*RM*RM
     const int g = blockIdx.x, tid = threadIdx.x, RM = P.RM;
     GroupState &gs = P.gs[g];
@@ -1214,6 +1216,7 @@ __device__ __forceinline__ void exch_apply_group(const DevProb &P, int g);
 // MAX all-reduce (:861), stage 1: combine the groups of this GPU into redsend[0..2]
 __global__ void k_exch_localmax(DevProb P)
 {
+    if (P.ctl[0]) return;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double a = -1e300, b = -1e300, c = -1e300;
     for (int g = 0; g < P.G; g++) { a = fmax(a, P.red[4 * g]); b = fmax(b, P.red[4 * g + 1]); c = fmax(c, P.red[4 * g + 2]); }
@@ -1244,13 +1247,14 @@ __device__ __forceinline__ void exch_apply_group(const DevProb &P, int g)
     }
 }
 
-__global__ __launch_bounds__(256) void k_exch_pack(DevProb P) { exch_pack_group(P, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_exch_pack(DevProb P) { if (P.ctl[0]) return; exch_pack_group(P, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_exch_apply(DevProb P) { exch_apply_group(P, blockIdx.x); }
 
 // MAX all-reduce result (:867-870, :961) folded into the apply launch: every block reduces the same inputs and
 // writes only its own group.  from_recv: P.redrecv already holds the job-wide maxima (after the RCCL all-reduce)
 __global__ __launch_bounds__(256) void k_exch_max_apply(DevProb P, int from_recv, int do_apply)
 {
+    if (P.ctl[0]) return;
     const int g = blockIdx.x;
     if (threadIdx.x == 0) {
         double a = -1e300, b = -1e300, c = -1e300;
@@ -1269,6 +1273,7 @@ __global__ __launch_bounds__(256) void k_exch_max_apply(DevProb P, int from_recv
 template <int FUN>
 __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
 {
+    if (P.ctl[0]) return;
     extern __shared__ __align__(16) double dyn[];
     __shared__ double s_bc;
     const int g = blockIdx.y, tid = threadIdx.x, m = P.d;
@@ -1349,6 +1354,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
 // block, run redundantly by every GPU on the all-reduced P.qall so that every rank holds the same value
 __global__ __launch_bounds__(256) void k_quad_tree(DevProb P)
 {
+    if (P.ctl[2]) return;
     const int tid = threadIdx.x, RM = P.RM, ng = P.nprocs;
     __shared__ int mym[256], myn[256];
     const double *part = P.qall, *dims = P.qall + (size_t)ng * RM * RM;
@@ -1382,9 +1388,50 @@ __global__ __launch_bounds__(256) void k_quad_tree(DevProb P)
 }
 
 // per-sweep summary of this GPU in the job-wide layout (slots of other GPUs stay zero; SUM all-reduce)
+// end of a sweep on the main stream: ranks and the stop flag as the forked quadrature must see them
+__global__ void k_fork(DevProb P)
+{
+    const int n = P.G * (P.d + 2);
+    for (int x = threadIdx.x; x < n; x += blockDim.x) P.rq[x] = P.r[x];
+    if (threadIdx.x == 0) P.ctl[2] = P.ctl[0];
+}
+// the reference's stopping rule on the job-wide summary (after its all-reduce), lib/dmrgg.f90:1011-1019
+__global__ void k_ctl(DevProb P, int it)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || P.ctl[0]) return;
+    const double *o = P.sumrecv;
+    int ready = (it + 1 >= P.maxrank);
+    if (P.accuracy >= 0.0) {
+        if (o[SUM_PMAX] <= P.accuracy * o[SUM_AMAX]) P.ctl[1]++; else P.ctl[1] = 0;
+        ready = ready || (P.ctl[1] >= 3);
+    }
+    P.ctl[0] = ready;
+}
+__device__ __forceinline__ void collect_summary(const DevProb &P);
 __global__ void k_collect(DevProb P)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0 || blockIdx.x != 0 || P.ctl[0]) return;
+    collect_summary(P);
+}
+// single-GPU end of sweep in one launch: snapshot for the forked quadrature, summary, stopping rule
+__global__ void k_sweep_end(DevProb P, int it)
+{
+    const int n = P.G * (P.d + 2);
+    for (int x = threadIdx.x; x < n; x += blockDim.x) P.rq[x] = P.r[x];
+    if (threadIdx.x != 0) return;
+    P.ctl[2] = P.ctl[0];
+    if (P.ctl[0]) return;
+    collect_summary(P);
+    const double *o = P.sumsend;
+    int ready = (it + 1 >= P.maxrank);
+    if (P.accuracy >= 0.0) {
+        if (o[SUM_PMAX] <= P.accuracy * o[SUM_AMAX]) P.ctl[1]++; else P.ctl[1] = 0;
+        ready = ready || (P.ctl[1] >= 3);
+    }
+    P.ctl[0] = ready;
+}
+__device__ __forceinline__ void collect_summary(const DevProb &P)
+{
     const int m = P.d;
     double *o = P.sumsend;
     double nev = 0.0, by = 0.0, nr = 0.0;
