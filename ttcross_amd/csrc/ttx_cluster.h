@@ -20,6 +20,31 @@
 
 #define CB 256      // threads of a cluster workgroup
 
+// Ising C integrand from VALUE rows, with the two running sums resumed from per-row prefix states: (pv, pvk) is the
+// state of the descending sum after the right row bn (dims A+3..m), (pw, pwk) the state of the ascending sum after
+// the left row an (dims 1..A).  The states are produced by exactly the operations f_ising_c4v would perform, so the
+// result is bit-identical; per element this saves one of the three passes over the m dimensions.
+__device__ __forceinline__ double f_ising_c4p(int m, int A, const double *an, const double *aw, double s1n, double s1w,
+                                              double s2n, double s2w, const double *bn, const double *bw,
+                                              double pv, double pvk, double pw, double pwk)
+{
+    const int nb = m - A - 2;
+    double v = pv, w = pw, vk = pvk, wk = pwk;
+    auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
+    auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
+    vstep(s2n); vstep(s1n);
+    chain8v<true>(an, A, vstep);
+    wstep(s1n); wstep(s2n);
+    chain8v<false>(bn, nb, wstep);
+    double b = 1.0 / (v * w);
+    double f = 2 * b;
+    auto fstep = [&](double xv) { f = f * xv; };
+    chain8v<false>(aw, A, fstep);
+    fstep(s1w); fstep(s2w);
+    chain8v<false>(bw, nb, fstep);
+    return f;
+}
+
 // 16-byte records exchanged between the blocks of a cluster: one store / one load instruction each, agent scope
 // (sc1: the store goes through to the point of coherence, the load does not hit in the vector L1)
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -84,14 +109,14 @@ __device__ __forceinline__ bool cluster_sync(unsigned *ctr, unsigned target, int
 #define CST_END()
 #endif
 
-__global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int nsteps, int NB, int smode, int ldsinv, int epoch)
+__global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int nsteps, int NB, int smode, int ldsinv, int epoch, int zkeep)
 {
     extern __shared__ __align__(16) double dyn[];
     __shared__ int zc[128], zr[128], zcs[128], zrs[128], keepc[128], keepr[128];
     __shared__ int nzc, nzr, nsc, nsr, s_ok;
     __shared__ ttx_cdfseg segc[TTX_TABSEG], segr[TTX_TABSEG];
     __shared__ double sha[8], shv[8], shm[8]; __shared__ int shi[8];
-    __shared__ unsigned long long sA[2];
+    __shared__ double pLw[64], pLk[64], pRv[64], pRk[64];   // prefix states of the two running sums per left / right row
     const int bid = blockIdx.x;
     const int g = (bid & 7) + 8 * (bid / (8 * NB)), cb = (bid >> 3) % NB;     // cluster of group g lives on XCD g % 8
     if (g >= P.G || P.ctl[0]) return;
@@ -120,12 +145,55 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
     int *lot = (int *)(xs + ((RM + 1) & ~1));          // 4 * nlotmax
     double *GL = (double *)(lot + 4 * ((2 * RM + 2 * NM + 4 + 1) & ~1));   // packed LU of bonds p-1 and p+1 (ldsinv only)
     double *GU = GL + (size_t)RM * RM;
+    // zkeep: the sorted distinct pivot rows / columns of EVERY own bond stay in LDS for the whole launch as keys
+    // (j << 16 | i), (q << 16 | k): built once, extended by insertion when a pivot is accepted.  Their order does not
+    // depend on the ranks, only the flattened positions do (recomputed per bond step).
+    int *ZK = (int *)(ldsinv ? GU + (size_t)RM * RM : GL);   // [nsteps][2][RM]
+    int *ZN = ZK + (size_t)nsteps * 2 * RM;                  // [nsteps][2]
     for (int x = tid; x < P.npar; x += CB) par[x] = P.par[x];
     if (cb == 0 && tid == 0) {                         // sweep start, :325-327
         int *rr = P.rr + (size_t)g * (m + 2);
         for (int s = 0; s <= m; s++) rr[s] = r[s];
     }
     __syncthreads();
+    if (zkeep) {
+        int *TMP = (int *)XL;                          // XL is staged later; free scratch for now: [nsteps][2][RM]
+        const int E = nbonds * 2 * RM;
+        for (int x = tid; x < E; x += CB) {            // raw keys
+            const int b = x / (2 * RM), side = (x / RM) & 1, u = x % RM, pb = first + b;
+            if (u < r[pb]) { const int *vp = vip_ptr(P, g, pb, first) + 4 * u; TMP[x] = (vp[2 * side + 1] << 16) | vp[2 * side]; }
+        }
+        __syncthreads();
+        for (int x = tid; x < E; x += CB) {            // rank among the bond's keys (ties by position), scatter
+            const int b = x / (2 * RM), u = x % RM, nb_ = r[first + b];
+            if (u < nb_) {
+                const int *src = TMP + (x - u); const int a = src[u]; int ra = 0;
+                for (int t = 0; t < nb_; t++) ra += (src[t] < a) || (src[t] == a && t < u);
+                ZK[(x - u) + ra] = a;
+            }
+        }
+        __syncthreads();
+        for (int x = tid; x < E; x += CB) {            // drop repeats: position among the kept ones
+            const int b = x / (2 * RM), u = x % RM, nb_ = r[first + b];
+            if (u < nb_) {
+                const int *src = ZK + (x - u); int pc = 0;
+                for (int t = 1; t <= u; t++) pc += (src[t] != src[t - 1]);
+                const bool keep = (u == 0) || (src[u] != src[u - 1]);
+                TMP[x] = keep ? pc : -1;
+                if (u == nb_ - 1) ZN[x / RM] = pc + 1;
+            }
+        }
+        __syncthreads();
+        int mykey = 0, mypos = -1;
+        for (int x0 = 0; x0 < E; x0 += CB) {
+            const int x = x0 + tid;
+            mypos = -1;
+            if (x < E) { const int b = x / (2 * RM), u = x % RM; if (u < r[first + b]) { mypos = TMP[x]; mykey = ZK[x]; } }
+            __syncthreads();
+            if (mypos >= 0) ZK[(x - x % RM) + mypos] = mykey;
+            __syncthreads();
+        }
+    }
     double amax = gs.amax, pivotmax = -1.0, pivotmin = -1.0;
     const double pivotmax_prev = gs.pivotmax_prev;
     long long neval = gs.neval;
@@ -133,6 +201,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
     double bytes_half = gs.bytes_half; long long n_resid = gs.n_resid;
     int hcount = 0;                                    // half-steps exchanged so far (selects the record buffer)
     const unsigned long long bil0 = ttx_minstd_pow(2ull * tid);     // RNG jump of this thread's first lottery candidate
+    unsigned long long sA0 = ttx_minstd_pow(2 * rngpos + 1);
     CST_DECL;
 
     for (int pp = 1; pp <= nsteps; pp++) {
@@ -146,16 +215,28 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
         double *Ap = core_ptr(P, P.arg, g, p, first), *Aq = core_ptr(P, P.arg, g, p + 1, first);
         const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
-        // ---- stage the value tables of both pivot sets ----
-        for (int x = tid; x < r0 * VS; x += CB) {
-            const int c = x / VS, o = x - c * VS;
-            const int ix = (o < p - 1) ? (int)Lt[(size_t)o * RM + c] : 1;
-            XL[(size_t)c * 2 * VS + o] = par[ix - 1]; XL[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
-        }
-        for (int x = tid; x < r2 * VS; x += CB) {
-            const int c = x / VS, o = x - c * VS;
-            const int ix = (o < m - p - 1) ? (int)Rt[(size_t)o * RM + c] : 1;
-            XR[(size_t)c * 2 * VS + o] = par[ix - 1]; XR[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
+        // ---- stage the value tables of both pivot sets (only the dimensions that exist on either side, rounded up to
+        //      the 8-wide chunks the integrand reads; the walk over (row, dim) needs no division) ----
+        {
+            const int AL = min(VS, (p - 1 + 7) & ~7), AR = min(VS, (m - p - 1 + 7) & ~7);
+            if (AL > 0) {
+                int c = tid / AL, o = tid - c * AL;
+                const int dc = CB / AL, dO = CB - dc * AL;
+                while (c < r0) {
+                    const int ix = (o < p - 1) ? (int)Lt[(size_t)o * RM + c] : 1;
+                    XL[(size_t)c * 2 * VS + o] = par[ix - 1]; XL[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
+                    c += dc; o += dO; if (o >= AL) { o -= AL; c++; }
+                }
+            }
+            if (AR > 0) {
+                int c = tid / AR, o = tid - c * AR;
+                const int dc = CB / AR, dO = CB - dc * AR;
+                while (c < r2) {
+                    const int ix = (o < m - p - 1) ? (int)Rt[(size_t)o * RM + c] : 1;
+                    XR[(size_t)c * 2 * VS + o] = par[ix - 1]; XR[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
+                    c += dc; o += dO; if (o >= AR) { o -= AR; c++; }
+                }
+            }
         }
         if (ldsinv) {                                  // neighbour LU factors for the fix-ups of the append (roles C, D)
             if (p > first) { const double *gL = inv_ptr(P, g, p - 1, first); for (int x = tid; x < r0 * r0; x += CB) GL[x] = gL[x]; }
@@ -163,8 +244,18 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         }
         CST(0);
         // ---- lottery (:410-484): every block draws and scores all candidates (identical results, no traffic) ----
-        if (tid == 32) sA[0] = ttx_minstd_pow(2 * rngpos + 1);
-        if (tid == 33) sA[1] = ttx_minstd_pow(2 * (rngpos + nlot) + 1);
+        // generator words of the two draw columns: 48271^(2*rngpos+1) and 48271^(2*(rngpos+nlot)+1), advanced from
+        // step to step by the small power 48271^(2*nlot) (every thread keeps them; no shared state, no barrier)
+        const unsigned long long stepmul = ttx_minstd_pow(2ull * nlot);
+        const unsigned long long sA1 = ttx_mulmod31(sA0, stepmul);
+        if (zkeep) {
+            const int b = p - first;
+            const int *kc = ZK + (size_t)b * 2 * RM, *kr = kc + RM;
+            if (tid == 0) { nzc = ZN[2 * b]; nzr = ZN[2 * b + 1]; }
+            if (tid < ZN[2 * b]) zc[tid] = ((kc[tid] & 0xffff) - 1) + r0 * ((kc[tid] >> 16) - 1) + 1;
+            if (tid < ZN[2 * b + 1]) zr[tid] = ((kr[tid] & 0xffff) - 1) + n2 * ((kr[tid] >> 16) - 1) + 1;
+            __syncthreads();
+        } else {
         const int *vp = vip_ptr(P, g, p, first);
         if (tid < r1) {
             zc[tid] = (vp[4 * tid + 0] - 1) + r0 * (vp[4 * tid + 1] - 1) + 1;
@@ -187,22 +278,38 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             if (tid == r1 - 1) { nzc = pc + keepc[tid]; nzr = pr + keepr[tid]; }
         }
         __syncthreads();
+        }
+        CST(1);
         const int Kc = r0 * n1 - nzc, Kr = n2 * r2 - nzr;
         if (tid < 64) { if (tid < P.cdf_ns[Kc]) segc[tid] = P.cdf_tab[(size_t)Kc * TTX_TABSEG + tid]; if (tid == 0) nsc = P.cdf_ns[Kc]; }
         else if (tid < 128) { const int t2 = tid - 64; if (t2 < P.cdf_ns[Kr]) segr[t2] = P.cdf_tab[(size_t)Kr * TTX_TABSEG + t2]; if (t2 == 0) nsr = P.cdf_ns[Kr]; }
+        if (tid < r0) {                                // ascending sum over the left row (dims 1..p-1)
+            double w = 1.0, wk = 1.0;
+            auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
+            chain8v<false>(XL + (size_t)tid * 2 * VS, p - 1, wstep);
+            pLw[tid] = w; pLk[tid] = wk;
+        } else if (tid >= 64 && tid < 64 + r2) {       // descending sum over the right row (dims p+2..m)
+            const int c = tid - 64;
+            double v = 1.0, vk = 1.0;
+            auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
+            chain8v<true>(XR + (size_t)c * 2 * VS, m - p - 1, vstep);
+            pRv[c] = v; pRk[c] = vk;
+        }
         __syncthreads();
-        CST(1);
+        CST(2);
         double ma = 0.0, ba = -1.0, bv = 0.0; int bi = INT_MAX;
         for (int il = tid; il < nlot; il += CB) {
             const unsigned long long bil = (il == tid) ? bil0 : ttx_minstd_pow(2ull * il);
-            const double d1 = ttx_flang_from_word(ttx_mulmod31(sA[0], bil)), d2 = ttx_flang_from_word(ttx_mulmod31(sA[1], bil));
+            const double d1 = ttx_flang_from_word(ttx_mulmod31(sA0, bil)), d2 = ttx_flang_from_word(ttx_mulmod31(sA1, bil));
             const int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);
             const int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
+            CST(3);
             const int i = (x - 1) % r0 + 1, j = (x - 1) / r0 + 1, k = (y - 1) % n2 + 1, q = (y - 1) / n2 + 1;
             lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
             const double *rl = XL + (size_t)(i - 1) * 2 * VS, *rq = XR + (size_t)(q - 1) * 2 * VS;
-            const double f = f_ising_c4v(m, p - 1, rl, rl + VS, par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], rq, rq + VS);
+            const double f = f_ising_c4p(m, p - 1, rl, rl + VS, par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], rq, rq + VS, pRv[q - 1], pRk[q - 1], pLw[i - 1], pLk[i - 1]);
             ma = fmax(ma, fabs(f));
+            CST(4);
             const double *c = Cp + (i - 1) + (size_t)RM * (j - 1), *w = Wq + (k - 1) + (size_t)NM * (q - 1);
             double t = 0.0;
 #pragma unroll 8
@@ -210,13 +317,21 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             const double b = f - t, aa = fabs(b);
             if (aa > ba || (aa == ba && il < bi)) { ba = aa; bv = b; bi = il; }
         }
-        ma = block_max(ma, sha);
+        ma = wave_max(ma);
+        wave_argmax(ba, bv, bi);
+        if (lane == 0) { shm[wv] = ma; sha[wv] = ba; shv[wv] = bv; shi[wv] = bi; }
+        __syncthreads();
+        ma = shm[0]; ba = sha[0]; bv = shv[0]; bi = shi[0];
+        for (int x = 1; x < CB / 64; x++) {
+            ma = fmax(ma, shm[x]);
+            if (sha[x] > ba || (sha[x] == ba && shi[x] < bi)) { ba = sha[x]; bv = shv[x]; bi = shi[x]; }
+        }
         amax = fmax(amax, ma);
-        fused_argmax(ba, bv, bi, sha, shv, shi);
         neval += nlot; rngpos += 2ull * nlot;
+        sA0 = ttx_mulmod31(sA1, stepmul);
         int ii = lot[4 * bi], jj = lot[4 * bi + 1], kk = lot[4 * bi + 2], qq = lot[4 * bi + 3];
         double pivot = bv;
-        CST(2);
+        CST(5);
         // ---- rook half-steps (:516-582) / piv = 0 (:492-513): own slice, then one record per block ----
         int havecol = 0, haverow = 0, crs = 0, done = 0;
         int rc_k = -1, rc_q = -1, rr_i = -1, rr_j = -1;     // pivot at which resc / resr were computed (-1: not valid)
@@ -234,7 +349,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             const bool resid = (P.piv != 0) && !dn;
             if (iscol) { rc_k = resid ? kk : -1; rc_q = qq; } else { rr_i = resid ? ii : -1; rr_j = jj; }
             __syncthreads();
-            CST(3);
+            CST(6);
             double mx = 0.0, ab = -1.0, bb = 0.0; int ix = INT_MAX;
             for (int u = tid; u < nsl; u += CB) {
                 double a;
@@ -242,7 +357,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     const int i = u % r0, j = jlo + u / r0, t = i + r0 * j;
                     const double *rl = XL + (size_t)i * 2 * VS, *rq = XR + (size_t)(qq - 1) * 2 * VS;
                     const double *c = Cp + i + (size_t)RM * j;
-                    a = f_ising_c4v(m, p - 1, rl, rl + VS, par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], rq, rq + VS);
+                    a = f_ising_c4p(m, p - 1, rl, rl + VS, par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], rq, rq + VS, pRv[qq - 1], pRk[qq - 1], pLw[i], pLk[i]);
                     fib[u] = a;
                     if (resid) {
                         double b = a;
@@ -256,7 +371,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     const int k = klo + u % nk, q = u / nk, t = k + n2 * q;
                     const double *rl = XL + (size_t)(ii - 1) * 2 * VS, *rq = XR + (size_t)q * 2 * VS;
                     const double *w = Wq + k + (size_t)NM * q;
-                    a = f_ising_c4v(m, p - 1, rl, rl + VS, par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], rq, rq + VS);
+                    a = f_ising_c4p(m, p - 1, rl, rl + VS, par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], rq, rq + VS, pRv[q], pRk[q], pLw[ii - 1], pLk[ii - 1]);
                     fib[u] = a;
                     if (resid) {
                         double tt = 0.0;
@@ -270,7 +385,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 }
                 mx = fmax(mx, fabs(a));
             }
-            CST(4);
+            CST(7);
             mx = wave_max(mx);
             wave_argmax(ab, bb, ix);
             if (lane == 0) { shm[wv] = mx; sha[wv] = ab; shv[wv] = bb; shi[wv] = ix; }
@@ -293,7 +408,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     rb.x = (unsigned)um; rb.y = (unsigned)(um >> 32); rb.z = gen; rb.w = 0;
                     st16(&buf[cb].a, ra); st16(&buf[cb].b, rb);
                 }
-                CST(5);
+                CST(8);
                 int ok = 1;
                 mx = 0.0; ab = -1.0; bb = 0.0; ix = INT_MAX;
                 if (lane < NB) {
@@ -322,7 +437,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             }
             __syncthreads();
             if (!s_ok) return;
-            CST(6);
+            CST(9);
             mx = shm[0]; ab = sha[0]; bb = shv[0]; ix = shi[0];
             hcount++;
             amax = fmax(amax, mx);
@@ -337,7 +452,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             }
         }
         __syncthreads();
-        CST(7);
+        CST(10);
         // ---- acceptance and in-place append (:598-758): every block appends its own slice ----
         int *tape = P.tape + ((size_t)g * (m + 2) + p) * 4;
         const bool upd = (fabs(pivot) > P.small_element * amax) && (fabs(pivot) > P.small_pivot * pivotmax_prev);
@@ -386,7 +501,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     Wq[o + P.SW * r1] = a + (-1.0) * tt;
                 }
             }
-            CST(8);
+            CST(11);
             // role C: row(p)(:, j, r1+1) = L(p-1)^-1 acol1(:, j)  (:715-728): one wave per own column
             if (p > first) {
                 const double *gL = ldsinv ? GL : inv_ptr(P, g, p - 1, first);
@@ -404,16 +519,17 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     if (lane < r0) Wp[j + (size_t)NM * r1 + P.SW * lane] = xf;
                 }
             }
+            CST(12);
             // role D: col(p+1)(r1+1, k, :) = arow1(k, :) U(p+1)^-1  (:730-749): one wave per own row
             if (p < last) {
                 const double *gU = ldsinv ? GU : inv_ptr(P, g, p + 1, first);
                 double *Cq = core_ptr(P, P.col, g, p + 1, first);
+                const double rdg = (lane < r2) ? 1.0 / gU[(lane + 1) * (lane + 1) - 1] : 0.0;   // 1/U(s,s) held by lane s
                 for (int kl = wv; kl < nk; kl += CB / 64) {
                     const int k = klo + kl;
                     double y = (lane < r2) ? arow[kl + nk * lane] : 0.0;
                     for (int s = 0; s < r2; s++) {
-                        const double dg = gU[(s + 1) * (s + 1) - 1];
-                        const double cand = (1.0 / dg) * y;
+                        const double cand = rdg * y;          // only lane s's product is used: (1.0 / U(s,s)) * y_s
                         const double ys = __shfl(cand, s, 64);
                         if (lane == s) y = ys;
                         if (lane > s && lane < r2) y = y + (-gU[lane * lane + lane + s]) * ys;
@@ -421,6 +537,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     if (lane < r2) Cq[r1 + (size_t)RM * k + P.SS * lane] = y;
                 }
             }
+            CST(13);
             // role E: index tables, pivot set, scalars (:604-635)
             if (cb == 0) {
                 short *Ln = L_ptr(P, g, p, first), *Rn = R_ptr(P, g, p, first);
@@ -434,15 +551,37 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     r[p] = r1 + 1;                                                      // :752
                 }
             }
+            if (zkeep) {                               // keep the sorted distinct lists of this bond current
+                const int b = p - first;
+                int *kc = ZK + (size_t)b * 2 * RM, *kr = kc + RM;
+                const int nc = ZN[2 * b], nr_ = ZN[2 * b + 1];
+                const int keyc = (jj << 16) | ii, keyr = (qq << 16) | kk;
+                int vc = 0, vr = 0;
+                if (tid < nc) vc = kc[tid];
+                if (tid < nr_) vr = kr[tid];
+                if (tid == 0) { nzc = 0; nzr = 0; }     // "already there" flags
+                __syncthreads();
+                if (tid < nc && vc == keyc) nzc = 1;
+                if (tid < nr_ && vr == keyr) nzr = 1;
+                __syncthreads();
+                const int dupc = nzc, dupr = nzr;
+                if (!dupc) { if (tid < nc && vc > keyc) kc[tid + 1] = vc; }
+                if (!dupr) { if (tid < nr_ && vr > keyr) kr[tid + 1] = vr; }
+                __syncthreads();
+                if (tid == 0) {
+                    if (!dupc) { int pos = 0; while (pos < nc && kc[pos] < keyc) pos++; kc[pos] = keyc; ZN[2 * b] = nc + 1; }
+                    if (!dupr) { int pos = 0; while (pos < nr_ && kr[pos] < keyr) pos++; kr[pos] = keyr; ZN[2 * b + 1] = nr_ + 1; }
+                }
+            }
             const double ap = fabs(pivot);
             pivotmax = (pivotmax < 0.0) ? ap : fmax(pivotmax, ap);
             pivotmin = (pivotmin < 0.0) ? ap : fmin(pivotmin, ap);
         }
-        CST(9);
+        CST(14);
         // end of the bond step: appends and the new rank become visible to the whole cluster (every block read r[] of
         // this step before its first half-step barrier, so block 0 may already have overwritten r[p])
         if (!cluster_sync(ctr, (++nbar) * (unsigned)NB, P.cl_abort, &s_ok, smode)) return;
-        CST(10);
+        CST(15);
         CST_END();
     }
     if (cb == 0 && tid == 0) {

@@ -114,6 +114,7 @@ struct ttx_engine {
     hipEvent_t ev_fork = nullptr, ev_sum[2] = {nullptr, nullptr}, ev_val[2] = {nullptr, nullptr};
     double *h_sum_base = nullptr;       // pinned [2][SB]: summaries of the two sweeps in flight
     double *h_val = nullptr;            // pinned [2]: per-sweep quadrature values
+    int cluster_zkeep = 0;              // cluster kernel keeps the sorted pivot lists of all own bonds in LDS
     int cluster_ldsinv = 0;             // cluster kernel keeps the neighbour LU factors in LDS
     int cluster = 0;                    // workgroups per bond group of the cluster sweep kernel (ttx_cluster.h); 0: not used
     size_t lds_cluster = 0;
@@ -328,7 +329,11 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         const size_t SL = (size_t)RM * ((NM + NB - 1) / NB + 1);
         h->lds_cluster = sizeof(double) * (cfg->npar + 4 + 4 * RM * VS + 4 * SL + RM + 4) + sizeof(int) * 4 * (nlotmax + 4);
         if (h->lds_cluster + sizeof(double) * 2 * RM * RM <= 150 * 1024) { h->cluster_ldsinv = 1; h->lds_cluster += sizeof(double) * 2 * RM * RM; }
-        const bool cluster_ok = fastc && h->RM <= 128 && NB >= 2 && h->G * NB <= prop.multiProcessorCount && h->lds_cluster <= 150 * 1024;
+        {
+            const size_t zk = sizeof(int) * ((size_t)h->nbmax * 2 * RM + 2 * h->nbmax + 4);
+            if (h->lds_cluster + zk <= 150 * 1024) { h->cluster_zkeep = 1; h->lds_cluster += zk; }
+        }
+        const bool cluster_ok = fastc && h->RM <= 64 && NB >= 2 && h->G * NB <= prop.multiProcessorCount && h->lds_cluster <= 150 * 1024;
         if (want == "cluster") { if (cluster_ok) h->cluster = NB; }
         else if (want == "fused") { if (fused_ok) h->fused = 1; }
         else if (want == "auto") { if (cluster_ok) h->cluster = NB; else if (fused_ok && h->G == 1) h->fused = 1; }
@@ -651,7 +656,7 @@ static int run_impl(ttx_engine *h)
         if (h->cluster) {
             KScope ks(h, TTX_K_HALFSTEP, 1);
             hipLaunchKernelGGL(k_sweep_cluster, dim3(8 * h->cluster * ((G + 7) / 8)), dim3(CB), h->lds_cluster, st, P, dir, h->nbmax, h->cluster,
-                               getenv("TTX_CLUSTER_SYNC") ? atoi(getenv("TTX_CLUSTER_SYNC")) : 1, h->cluster_ldsinv, it_);
+                               getenv("TTX_CLUSTER_SYNC") ? atoi(getenv("TTX_CLUSTER_SYNC")) : 1, h->cluster_ldsinv, it_, h->cluster_zkeep);
         } else if (h->fused) {
             KScope ks(h, TTX_K_HALFSTEP, 1);
             hipLaunchKernelGGL(k_sweep_fused, dim3(G), dim3(FB), h->lds_fused, st, P, dir, h->nbmax);
@@ -785,7 +790,7 @@ static int run_impl(ttx_engine *h)
         HIPCHECK(hipMemcpy(&g0s, P.gs, sizeof(GroupState), hipMemcpyDeviceToHost));
         for (int k = 0; k < 2; k++) {
             fprintf(stderr, "stamps kernel %d (n=%lld):", k, g0s.nstamp[k]);
-            for (int x = 0; x < 12; x++) fprintf(stderr, " %.2fus", g0s.nstamp[k] ? 0.01 * (double)g0s.stamp[k][x] / (double)g0s.nstamp[k] : 0.0);
+            for (int x = 0; x < 16; x++) fprintf(stderr, " %.2fus", g0s.nstamp[k] ? 0.01 * (double)g0s.stamp[k][x] / (double)g0s.nstamp[k] : 0.0);
             fprintf(stderr, "\n");
         }
     }
