@@ -141,8 +141,9 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
     double *arow = acol + SL;                          // own slice of the row fiber
     double *resc = arow + SL;                          // residuals of the own column / row slice at the last half-step
     double *resr = resc + SL;                          // that computed them (reused by the append, roles A and B)
-    double *xs = resr + SL;                            // RM
-    int *lot = (int *)(xs + ((RM + 1) & ~1));          // 4 * nlotmax
+    double *xsc = resr + SL;                           // RM: row-factor entries at the pivot column (kk, qq) ...
+    double *xsr = xsc + ((RM + 1) & ~1);               // RM: column-factor entries at the pivot row (ii, jj)
+    int *lot = (int *)(xsr + ((RM + 1) & ~1));         // 4 * nlotmax
     double *GL = (double *)(lot + 4 * ((2 * RM + 2 * NM + 4 + 1) & ~1));   // packed LU of bonds p-1 and p+1 (ldsinv only)
     double *GU = GL + (size_t)RM * RM;
     // zkeep: the sorted distinct pivot rows / columns of EVERY own bond stay in LDS for the whole launch as keys
@@ -335,14 +336,16 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         // ---- rook half-steps (:516-582) / piv = 0 (:492-513): own slice, then one record per block ----
         int havecol = 0, haverow = 0, crs = 0, done = 0;
         int rc_k = -1, rc_q = -1, rr_i = -1, rr_j = -1;     // pivot at which resc / resr were computed (-1: not valid)
+        int xc_k = -1, xc_q = -1, xr_i = -1, xr_j = -1;     // pivot at which xsc / xsr were loaded
         const int H = (P.piv == 0) ? 2 : 2 * P.piv;
         for (int h = 0; h < H && !done; h++) {
             const bool iscol = (P.piv == 0) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);
             const int nf = iscol ? r0 * n1 : n2 * r2;
             const int nsl = iscol ? r0 * nj : nk * r2;
             double *fib = iscol ? acol : arow;
-            if (iscol) for (int s = tid; s < r1; s += CB) xs[s] = Wq[(kk - 1) + (size_t)NM * (qq - 1) + P.SW * s];
-            else       for (int s = tid; s < r1; s += CB) xs[s] = Cp[(ii - 1) + (size_t)RM * (jj - 1) + P.SS * s];
+            double *xs = iscol ? xsc : xsr;
+            if (iscol) { for (int s = tid; s < r1; s += CB) xs[s] = Wq[(kk - 1) + (size_t)NM * (qq - 1) + P.SW * s]; xc_k = kk; xc_q = qq; }
+            else       { for (int s = tid; s < r1; s += CB) xs[s] = Cp[(ii - 1) + (size_t)RM * (jj - 1) + P.SS * s]; xr_i = ii; xr_j = jj; }
             crs++;
             if (iscol) havecol = 1; else haverow = 1;
             const int dn = (P.piv == 0) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));
@@ -461,15 +464,15 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         } else {
             const int i0 = ii - 1, j0 = jj - 1, k0 = kk - 1, q0 = qq - 1;
             double *gI = inv_ptr(P, g, p, first);
+            // the factor entries at the final pivot were loaded by the last column / row half-step; reload only if not
+            const bool haveC = (xc_k == kk && xc_q == qq), haveR = (xr_i == ii && xr_j == jj);
+            if (!haveC) for (int s = tid; s < r1; s += CB) xsc[s] = Wq[k0 + (size_t)NM * q0 + P.SW * s];
+            if (!haveR) for (int s = tid; s < r1; s += CB) xsr[s] = Cp[i0 + (size_t)RM * j0 + P.SS * s];
+            if (!haveC || !haveR) __syncthreads();
             // role E first part: packed LU from the OLD factors (:649-660)
             if (cb == 0)
-                for (int s = tid; s < r1; s += CB) {
-                    gI[r1 * r1 + s] = Cp[i0 + (size_t)RM * j0 + P.SS * s];
-                    gI[r1 * r1 + r1 + s] = Wq[k0 + (size_t)NM * q0 + P.SW * s];
-                }
+                for (int s = tid; s < r1; s += CB) { gI[r1 * r1 + s] = xsr[s]; gI[r1 * r1 + r1 + s] = xsc[s]; }
             // role A: arg(p), col(p) new slab (:662-668, :701)
-            for (int s = tid; s < r1; s += CB) xs[s] = Wq[k0 + (size_t)NM * q0 + P.SW * s];
-            __syncthreads();
             const bool reuseA = (rc_k == kk && rc_q == qq), reuseB = (rr_i == ii && rr_j == jj);
             for (int u = tid; u < r0 * nj; u += CB) {
                 const int i = u % r0, j = jlo + u / r0; const size_t o = i + (size_t)RM * j;
@@ -480,14 +483,11 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 else {
                     y = a;
 #pragma unroll 16
-                    for (int s = 0; s < r1; s++) y = y + (-xs[s]) * Cp[o + P.SS * s];
+                    for (int s = 0; s < r1; s++) y = y + (-xsc[s]) * Cp[o + P.SS * s];
                 }
                 Cp[o + P.SS * r1] = (1.0 / pivot) * y;
             }
-            __syncthreads();
             // role B: arg(p+1), row(p+1) new row (:669-674, :702)
-            for (int s = tid; s < r1; s += CB) xs[s] = Cp[i0 + (size_t)RM * j0 + P.SS * s];
-            __syncthreads();
             for (int u = tid; u < nk * r2; u += CB) {
                 const int k = klo + u % nk, q = u / nk;
                 const double a = arow[u];
@@ -497,44 +497,50 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 else {
                     double tt = 0.0;
 #pragma unroll 16
-                    for (int s = 0; s < r1; s++) tt = tt + Wq[o + P.SW * s] * xs[s];
+                    for (int s = 0; s < r1; s++) tt = tt + Wq[o + P.SW * s] * xsr[s];
                     Wq[o + P.SW * r1] = a + (-1.0) * tt;
                 }
             }
             CST(11);
-            // role C: row(p)(:, j, r1+1) = L(p-1)^-1 acol1(:, j)  (:715-728): one wave per own column
+            // roles C and D are triangular solves along the rank index, one per own column j / row k.  A solve occupies
+            // r0 (r2) lanes: with ranks up to 32 two of them share a wave (shuffles of width 32).
+            // role C: row(p)(:, j, r1+1) = L(p-1)^-1 acol1(:, j)  (:715-728)
             if (p > first) {
                 const double *gL = ldsinv ? GL : inv_ptr(P, g, p - 1, first);
                 double *Wp = core_ptr(P, P.row, g, p, first);
-                for (int jl = wv; jl < nj; jl += CB / 64) {
-                    const int j = jlo + jl;
-                    const double a = (lane < r0) ? acol[lane + r0 * jl] : 0.0;
+                const int pk = (r0 <= 32) ? 2 : 1, lw = 64 / pk, l = lane & (lw - 1), sub = lane / lw;
+                for (int base = wv * pk; base < nj; base += (CB / 64) * pk) {
+                    const int jl = base + sub, j = jlo + jl;
+                    const bool on = (jl < nj) && (l < r0);
+                    const double a = on ? acol[l + r0 * jl] : 0.0;
                     double tmp = 0.0, xf = 0.0;
                     for (int s = 0; s < r0; s++) {
                         const double cand = (s == 0) ? a : a + (-1.0) * tmp;
-                        const double xsv = __shfl(cand, s, 64);
-                        if (lane == s) xf = xsv;
-                        if (lane > s && lane < r0) tmp = tmp + xsv * gL[lane * lane + s];
+                        const double xsv = __shfl(cand, s, lw);
+                        if (l == s) xf = xsv;
+                        if (l > s && l < r0) tmp = tmp + xsv * gL[l * l + s];
                     }
-                    if (lane < r0) Wp[j + (size_t)NM * r1 + P.SW * lane] = xf;
+                    if (on) Wp[j + (size_t)NM * r1 + P.SW * l] = xf;
                 }
             }
             CST(12);
-            // role D: col(p+1)(r1+1, k, :) = arow1(k, :) U(p+1)^-1  (:730-749): one wave per own row
+            // role D: col(p+1)(r1+1, k, :) = arow1(k, :) U(p+1)^-1  (:730-749)
             if (p < last) {
                 const double *gU = ldsinv ? GU : inv_ptr(P, g, p + 1, first);
                 double *Cq = core_ptr(P, P.col, g, p + 1, first);
-                const double rdg = (lane < r2) ? 1.0 / gU[(lane + 1) * (lane + 1) - 1] : 0.0;   // 1/U(s,s) held by lane s
-                for (int kl = wv; kl < nk; kl += CB / 64) {
-                    const int k = klo + kl;
-                    double y = (lane < r2) ? arow[kl + nk * lane] : 0.0;
+                const int pk = (r2 <= 32) ? 2 : 1, lw = 64 / pk, l = lane & (lw - 1), sub = lane / lw;
+                const double rdg = (l < r2) ? 1.0 / gU[(l + 1) * (l + 1) - 1] : 0.0;   // 1/U(s,s) held by lane s
+                for (int base = wv * pk; base < nk; base += (CB / 64) * pk) {
+                    const int kl = base + sub, k = klo + kl;
+                    const bool on = (kl < nk) && (l < r2);
+                    double y = on ? arow[kl + nk * l] : 0.0;
                     for (int s = 0; s < r2; s++) {
                         const double cand = rdg * y;          // only lane s's product is used: (1.0 / U(s,s)) * y_s
-                        const double ys = __shfl(cand, s, 64);
-                        if (lane == s) y = ys;
-                        if (lane > s && lane < r2) y = y + (-gU[lane * lane + lane + s]) * ys;
+                        const double ys = __shfl(cand, s, lw);
+                        if (l == s) y = ys;
+                        if (l > s && l < r2) y = y + (-gU[l * l + l + s]) * ys;
                     }
-                    if (lane < r2) Cq[r1 + (size_t)RM * k + P.SS * lane] = y;
+                    if (on) Cq[r1 + (size_t)RM * k + P.SS * l] = y;
                 }
             }
             CST(13);
@@ -551,26 +557,17 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     r[p] = r1 + 1;                                                      // :752
                 }
             }
-            if (zkeep) {                               // keep the sorted distinct lists of this bond current
-                const int b = p - first;
-                int *kc = ZK + (size_t)b * 2 * RM, *kr = kc + RM;
-                const int nc = ZN[2 * b], nr_ = ZN[2 * b + 1];
-                const int keyc = (jj << 16) | ii, keyr = (qq << 16) | kk;
-                int vc = 0, vr = 0;
-                if (tid < nc) vc = kc[tid];
-                if (tid < nr_) vr = kr[tid];
-                if (tid == 0) { nzc = 0; nzr = 0; }     // "already there" flags
-                __syncthreads();
-                if (tid < nc && vc == keyc) nzc = 1;
-                if (tid < nr_ && vr == keyr) nzr = 1;
-                __syncthreads();
-                const int dupc = nzc, dupr = nzr;
-                if (!dupc) { if (tid < nc && vc > keyc) kc[tid + 1] = vc; }
-                if (!dupr) { if (tid < nr_ && vr > keyr) kr[tid + 1] = vr; }
-                __syncthreads();
-                if (tid == 0) {
-                    if (!dupc) { int pos = 0; while (pos < nc && kc[pos] < keyc) pos++; kc[pos] = keyc; ZN[2 * b] = nc + 1; }
-                    if (!dupr) { int pos = 0; while (pos < nr_ && kr[pos] < keyr) pos++; kr[pos] = keyr; ZN[2 * b + 1] = nr_ + 1; }
+            if (zkeep && wv < 2) {                     // keep the sorted distinct lists of this bond current:
+                const int b = p - first;               // wave 0 inserts the pivot row, wave 1 the pivot column (RM <= 64)
+                int *kl = ZK + (size_t)b * 2 * RM + (size_t)wv * RM;
+                const int nl = ZN[2 * b + wv];
+                const int key = wv == 0 ? ((jj << 16) | ii) : ((qq << 16) | kk);
+                const int v = (lane < nl) ? kl[lane] : INT_MAX;
+                const bool dup = __ballot(v == key) != 0ull;
+                const int pos = __popcll(__ballot(v < key));
+                if (!dup) {
+                    if (lane < nl && v > key) kl[lane + 1] = v;      // every lane has read its entry before any lane writes
+                    if (lane == 0) { kl[pos] = key; ZN[2 * b + wv] = nl + 1; }
                 }
             }
             const double ap = fabs(pivot);
