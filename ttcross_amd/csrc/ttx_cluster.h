@@ -581,8 +581,12 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         CST(15);
         CST_END();
     }
-    if (cb == 0 && tid == 0) {
-        gs.amax = amax; gs.pivotmax = pivotmax; gs.pivotmin = pivotmin; gs.neval = neval; gs.rngpos = rngpos;
-        gs.bytes_half = bytes_half; gs.n_resid = n_resid;
+    if (cb == 0) {
+        if (tid == 0) {
+            gs.amax = amax; gs.pivotmax = pivotmax; gs.pivotmin = pivotmin; gs.neval = neval; gs.rngpos = rngpos;
+            gs.bytes_half = bytes_half; gs.n_resid = n_resid;
+        }
+        __syncthreads();
+        exch_pack_group(P, g);          // the group's outgoing boundary messages (saves the separate k_exch_pack launch)
     }
 }

@@ -268,6 +268,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     }
     HIPCHECK(hipHostMalloc((void **)&h->h_sum_base, sizeof(double) * 2 * h->SB));
     h->h_sum = h->h_sum_base;
+    memset(h->h_sum_base, 0, sizeof(double) * 2 * h->SB);
     HIPCHECK(hipHostMalloc((void **)&h->h_val, sizeof(double) * 2));
     HIPCHECK(hipStreamCreateWithFlags(&h->qstream, hipStreamNonBlocking));
     HIPCHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -642,7 +643,7 @@ static int run_impl(ttx_engine *h)
     // On a single GPU the per-sweep quadrature (only reported, never fed back) runs on its own stream next to the
     // following sweep: it reads a snapshot of the ranks and only slabs that already exist (appends are in place).
     const bool pipe = (h->cluster || h->fused) && (h->W == 1 || h->comm) && !h->profile;
-    const bool forkq = pipe && h->W == 1 && P.has_quad;
+    const bool forkq = pipe && h->W == 1 && P.has_quad && !getenv("TTX_NOFORK");
     HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 4, st));
     if (h->cluster) {
         HIPCHECK(hipMemsetAsync(P.cl_ctr, 0, sizeof(unsigned) * G, st));
@@ -682,7 +683,7 @@ static int run_impl(ttx_engine *h)
         if (forkq) HIPCHECK(hipStreamWaitEvent(st, h->ev_val[slot ^ 1], 0));   // the previous quadrature is done with the boundaries
         {   // per-sweep exchange between bond groups (:763-961)
             KScope ks(h, TTX_K_EXCHANGE, (h->W > 1 ? 4 : 2) + (nproc > 1 ? 1 : 0));
-            hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
+            if (!h->cluster) hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);     // the cluster kernel packs at its end
             if (h->W > 1) {
                 hipLaunchKernelGGL(k_exch_localmax, dim3(1), dim3(64), 0, st, P);
                 if (int rc_ = xfer_neighbours(h)) return rc_;
@@ -693,7 +694,7 @@ static int run_impl(ttx_engine *h)
                 hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8), st, P);
         }
         const bool one_end = pipe && h->W == 1;      // snapshot + summary + stopping rule in one launch
-        if (one_end) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_);
+        if (one_end) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
         else if (pipe) hipLaunchKernelGGL(k_fork, dim3(1), dim3(256), 0, st, P);
         if (P.has_quad) {
             hipStream_t sq = forkq ? h->qstream : st;
@@ -717,7 +718,7 @@ static int run_impl(ttx_engine *h)
                 if (int rc_ = allreduce_dev(h, P.sumsend, P.sumrecv, h->SB, 0)) return rc_;
                 hipLaunchKernelGGL(k_ctl, dim3(1), dim3(64), 0, st, P, it_);
             }
-            HIPCHECK(hipMemcpyAsync(h->h_sum_base + (size_t)slot * h->SB, P.sumrecv, sizeof(double) * h->SB, hipMemcpyDeviceToHost, st));
+            if (!one_end) HIPCHECK(hipMemcpyAsync(h->h_sum_base + (size_t)slot * h->SB, P.sumrecv, sizeof(double) * h->SB, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipEventRecord(h->ev_sum[slot], st));
         }
         return TTX_OK;

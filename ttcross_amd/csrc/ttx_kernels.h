@@ -1413,19 +1413,31 @@ __global__ void k_collect(DevProb P)
     if (threadIdx.x != 0 || blockIdx.x != 0 || P.ctl[0]) return;
     collect_summary(P);
 }
-// single-GPU end of sweep in one launch: snapshot for the forked quadrature, summary, stopping rule
-__global__ void k_sweep_end(DevProb P, int it)
+// single-GPU end of sweep in one launch: snapshot for the forked quadrature, summary (written straight into the
+// pinned host slot `out`), stopping rule
+__global__ __launch_bounds__(256) void k_sweep_end(DevProb P, int it, double *out)
 {
-    const int n = P.G * (P.d + 2);
-    for (int x = threadIdx.x; x < n; x += blockDim.x) P.rq[x] = P.r[x];
-    if (threadIdx.x != 0) return;
-    P.ctl[2] = P.ctl[0];
+    const int n = P.G * (P.d + 2), m = P.d, tid = threadIdx.x;
+    for (int x = tid; x < n; x += blockDim.x) P.rq[x] = P.r[x];
+    if (tid == 0) P.ctl[2] = P.ctl[0];
     if (P.ctl[0]) return;
-    collect_summary(P);
-    const double *o = P.sumsend;
+    for (int p = 1 + tid; p < m; p += blockDim.x) {          // owner of bond p, its rank and tape entry
+        int g = 0;
+        while (g + 1 < P.G && P.gs[g + 1].first <= p) g++;
+        const int *r = P.r + (size_t)g * (m + 2), *tp = P.tape + (size_t)g * (m + 2) * 4;
+        double *e = out + SUM_HDR + P.nprocs + 5 * p;
+        e[0] = (double)r[p]; e[1] = (double)tp[4 * p]; e[2] = (double)tp[4 * p + 1]; e[3] = (double)tp[4 * p + 2]; e[4] = (double)tp[4 * p + 3];
+    }
+    if (tid < P.G) out[SUM_HDR + P.gs[tid].gglobal] = P.gs[tid].initval;
+    if (tid != 0) return;
+    double nev = 0.0, by = 0.0, nr = 0.0;
+    for (int g = 0; g < P.G; g++) { const GroupState &gs = P.gs[g]; nev += (double)gs.neval; by += gs.bytes_half; nr += (double)gs.n_resid; }
+    const double amax = P.gs[0].amax, pmax = P.gs[0].pivotmax;    // single GPU: local group 0 is global group 0
+    out[SUM_NEVAL] = nev; out[SUM_BYTES] = by; out[SUM_NRESID] = nr; out[SUM_AMAX] = amax; out[SUM_PMAX] = pmax; out[SUM_PMIN] = P.gs[0].pivotmin;
+    out[SUM_VAL] = 0.0;
     int ready = (it + 1 >= P.maxrank);
     if (P.accuracy >= 0.0) {
-        if (o[SUM_PMAX] <= P.accuracy * o[SUM_AMAX]) P.ctl[1]++; else P.ctl[1] = 0;
+        if (pmax <= P.accuracy * amax) P.ctl[1]++; else P.ctl[1] = 0;
         ready = ready || (P.ctl[1] >= 3);
     }
     P.ctl[0] = ready;
