@@ -637,13 +637,12 @@ static int run_impl(ttx_engine *h)
     bool ready = (it + 1 >= h->cfg.maxrank);
     const int nfb = (h->RM * h->NM + TTX_BLK - 1) / TTX_BLK;
     const size_t lds_acc = sizeof(double) * (h->RM + 2);
-    // Pipelined mode (whole-sweep kernels, device-resident transport): the stopping rule also runs on the device
-    // (k_ctl), so sweep it+1 is enqueued BEFORE the host has read the summary of sweep it -- the GPU never waits for
-    // the host.  When the rule fires, the one sweep that is already enqueued finds the stop flag and does nothing.
+    // Pipelined mode (whole-sweep kernels, one process): the stopping rule also runs on the device (k_sweep_end), so
+    // sweep it+1 is enqueued BEFORE the host has read the summary of sweep it -- the GPU never waits for the host.  When the rule fires, the one sweep that is already enqueued finds the stop flag and does nothing.
     // On a single GPU the per-sweep quadrature (only reported, never fed back) runs on its own stream next to the
     // following sweep: it reads a snapshot of the ranks and only slabs that already exist (appends are in place).
-    const bool pipe = (h->cluster || h->fused) && (h->W == 1 || h->comm) && !h->profile;
-    const bool forkq = pipe && h->W == 1 && P.has_quad && !getenv("TTX_NOFORK");
+    const bool pipe = (h->cluster || h->fused) && h->W == 1 && !h->profile;
+    const bool forkq = pipe && P.has_quad;
     HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 4, st));
     if (h->cluster) {
         HIPCHECK(hipMemsetAsync(P.cl_ctr, 0, sizeof(unsigned) * G, st));
@@ -691,11 +690,9 @@ static int run_impl(ttx_engine *h)
             }
             hipLaunchKernelGGL(k_exch_max_apply, dim3(G), dim3(256), 0, st, P, h->W > 1 ? 1 : 0, nproc > 1 ? 1 : 0);
             if (nproc > 1)
-                hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8), st, P);
+                hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8) + sizeof(double) * (64 * 64 + 4), st, P);
         }
-        const bool one_end = pipe && h->W == 1;      // snapshot + summary + stopping rule in one launch
-        if (one_end) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
-        else if (pipe) hipLaunchKernelGGL(k_fork, dim3(1), dim3(256), 0, st, P);
+        if (pipe) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
         if (P.has_quad) {
             hipStream_t sq = forkq ? h->qstream : st;
             if (forkq) { HIPCHECK(hipEventRecord(h->ev_fork, st)); HIPCHECK(hipStreamWaitEvent(sq, h->ev_fork, 0)); }
@@ -712,18 +709,10 @@ static int run_impl(ttx_engine *h)
                 HIPCHECK(hipEventRecord(h->ev_val[slot], sq));
             }
         }
-        if (pipe) {
-            if (!one_end) {
-                hipLaunchKernelGGL(k_collect, dim3(1), dim3(64), 0, st, P);
-                if (int rc_ = allreduce_dev(h, P.sumsend, P.sumrecv, h->SB, 0)) return rc_;
-                hipLaunchKernelGGL(k_ctl, dim3(1), dim3(64), 0, st, P, it_);
-            }
-            if (!one_end) HIPCHECK(hipMemcpyAsync(h->h_sum_base + (size_t)slot * h->SB, P.sumrecv, sizeof(double) * h->SB, hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipEventRecord(h->ev_sum[slot], st));
-        }
+        if (pipe) HIPCHECK(hipEventRecord(h->ev_sum[slot], st));     // k_sweep_end wrote the summary into the pinned slot
         return TTX_OK;
     };
-    // host side of a finished sweep: record, tapes, log line, stopping rule (identical to k_ctl)
+    // host side of a finished sweep: record, tapes, log line, stopping rule (identical to k_sweep_end)
     auto process_sweep = [&](int it_) -> int {
         const int dir = 2 - it_ % 2, slot = it_ & 1;
         if (pipe) {

@@ -1282,6 +1282,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
     const int *r = P.r + (size_t)g * (m + 2), *rr = P.rr + (size_t)g * (m + 2), *upd = P.upd + (size_t)g * (m + 2);
     double *par = dyn;
     short *row = (short *)(dyn + P.npar);      // one full multi-index (m shorts) for the corner evaluation
+    double *lu = dyn + P.npar + ((m + 8 + 3) >> 2) + 1;   // packed LU of the boundary bond (ranks <= 64)
     if ((int)blockIdx.x < P.NM) {
         const int k = blockIdx.x, p = last, br = last + 1;
         if (!P.inR[g] || !upd[br] || k >= P.n[br]) return;
@@ -1308,6 +1309,18 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
         // row(p+1)(:, k, new) = L(p)^-1 * column : d2_luar(n(p+1), r(p), inv(p), .) :940-951
         const double *gI = inv_ptr(P, g, p, first);
         double tmp = 0.0, xf = 0.0;
+        if (rp <= 64) {                               // one wave: the solve runs as a shuffle wavefront over LDS-staged LU
+            __syncthreads();
+            for (int x = tid; x < rp * rp; x += TTX_BLK) lu[x] = gI[x];
+            __syncthreads();
+            if (tid < 64)
+                for (int s = 0; s < rp; s++) {
+                    const double cand = (s == 0) ? a : a + (-1.0) * tmp;
+                    const double xsv = __shfl(cand, s, 64);
+                    if (tid == s) xf = xsv;
+                    if (tid > s && tid < rp) tmp = tmp + xsv * lu[tid * tid + s];
+                }
+        } else
         for (int s = 0; s < rp; s++) {
             if (tid == s) { xf = (s == 0) ? a : a + (-1.0) * tmp; s_bc = xf; }
             __syncthreads();
@@ -1340,6 +1353,20 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
         if (tid < rp) A[inew + (size_t)P.RM * j + P.SS * tid] = y;
         // col(p)(new, j, :) = row * U(p)^-1 : d2_lual(n(p), r(p), inv(p), .) dmrggmp.f90:622
         const double *gI = inv_ptr(P, g, p, first);
+        if (rp <= 64) {
+            __syncthreads();
+            for (int x = tid; x < rp * rp; x += TTX_BLK) lu[x] = gI[x];
+            __syncthreads();
+            if (tid < 64) {
+                const double rdg = (tid < rp) ? 1.0 / lu[(tid + 1) * (tid + 1) - 1] : 0.0;
+                for (int s = 0; s < rp; s++) {
+                    const double cand = rdg * y;          // only lane s's product is used
+                    const double ys = __shfl(cand, s, 64);
+                    if (tid == s) y = ys;
+                    if (tid > s && tid < rp) y = y + (-lu[tid * tid + tid + s]) * ys;
+                }
+            }
+        } else
         for (int s = 0; s < rp; s++) {
             if (tid == s) { y = (1.0 / gI[(s + 1) * (s + 1) - 1]) * y; s_bc = y; }
             __syncthreads();
@@ -1388,25 +1415,6 @@ __global__ __launch_bounds__(256) void k_quad_tree(DevProb P)
 }
 
 // per-sweep summary of this GPU in the job-wide layout (slots of other GPUs stay zero; SUM all-reduce)
-// end of a sweep on the main stream: ranks and the stop flag as the forked quadrature must see them
-__global__ void k_fork(DevProb P)
-{
-    const int n = P.G * (P.d + 2);
-    for (int x = threadIdx.x; x < n; x += blockDim.x) P.rq[x] = P.r[x];
-    if (threadIdx.x == 0) P.ctl[2] = P.ctl[0];
-}
-// the reference's stopping rule on the job-wide summary (after its all-reduce), lib/dmrgg.f90:1011-1019
-__global__ void k_ctl(DevProb P, int it)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0 || P.ctl[0]) return;
-    const double *o = P.sumrecv;
-    int ready = (it + 1 >= P.maxrank);
-    if (P.accuracy >= 0.0) {
-        if (o[SUM_PMAX] <= P.accuracy * o[SUM_AMAX]) P.ctl[1]++; else P.ctl[1] = 0;
-        ready = ready || (P.ctl[1] >= 3);
-    }
-    P.ctl[0] = ready;
-}
 __device__ __forceinline__ void collect_summary(const DevProb &P);
 __global__ void k_collect(DevProb P)
 {
