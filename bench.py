@@ -212,12 +212,17 @@ def main():
             t1.close()
     if rank != 0:
         return
+    path = tt.sweep_path()
+    kname = {"chain": "k_halfstep", "fused": "k_sweep_fused", "cluster": "k_sweep_cluster"}[path]
+    kdesc = {"chain": "k_halfstep (one rook half-step: fiber evaluation + residual + arg-max)",
+             "fused": "k_sweep_fused (whole sweep of a bond group in one workgroup; bytes = its rook half-steps)",
+             "cluster": "k_sweep_cluster (whole sweep of a bond group by a cluster of workgroups; bytes = its rook half-steps)"}[path]
     traffic = None
-    try:   # per-launch FETCH_SIZE + WRITE_SIZE of k_halfstep from the committed PMC passes of this same command
+    try:   # per-launch FETCH_SIZE + WRITE_SIZE of that kernel from the committed PMC passes of this same command
         import csv
         f = w = None
         for row in csv.reader(l for l in open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_c64_g8.csv")) if not l.startswith("#")):
-            if len(row) >= 6 and "k_halfstep" in row[1]:
+            if len(row) >= 6 and kname in row[1]:
                 if row[2] == "FETCH_SIZE":
                     f = float(row[5])
                 if row[2] == "WRITE_SIZE":
@@ -234,7 +239,7 @@ def main():
         "config": {"workload": desc, "driver": "test_crs_ising " + " ".join(str(x) for x in argv[1:]), "bond_groups": groups, "transport": transport,
                    "neval_per_step": neval // a.steps, "sweeps": nsweeps, "integral": value,
                    "rel_err_vs_analytic": abs(1 - value / s["tru"]) if s["tru"] else None},
-        "roofline": {"kernel": "k_halfstep (fiber evaluation + residual + arg-max)", "bound": "hbm", "achieved": achieved,
+        "roofline": {"kernel": kdesc, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_us": avg_us, "launches_per_step": hs["launches"] / max(1, min(a.steps, 3)),
                      "algorithmic_bytes_per_launch": bytes_per_launch},

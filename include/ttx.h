@@ -155,6 +155,10 @@ int ttx_get_modes(const ttx_engine *h, int32_t *d, int32_t *n);
 #define TTX_K_OTHER 5
 #define TTX_K_NKINDS 6
 int ttx_set_profile(ttx_engine *h, int on);
+/* which implementation of the sweep this engine uses (TTX_SWEEP=auto|chain|fused|cluster chooses at ttx_create):
+ * 0 multi-kernel chain (k_lottery / k_halfstep / k_accept per bond), 1 one workgroup per bond group for the whole
+ * sweep (k_sweep_fused), 2 a cluster of workgroups per bond group for the whole sweep (k_sweep_cluster) */
+int ttx_sweep_path(const ttx_engine *h);
 int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double ms[TTX_K_NKINDS], double bytes[TTX_K_NKINDS]);
 
 /* ---- kernel-level entry points used by the parity tests (host buffers in, host buffers out) ---- */

@@ -449,3 +449,31 @@ def test_fortran_ttio_dropin(tmp_path):
     assert ttio.same_file(tmp_path / "copy.tt", gold)
     l, n, r, cores = ttio.read_tt(tmp_path / "ones.tt")
     assert list(n) == [2, 3, 4, 5] and list(r) == [1] * 5 and all(np.all(c == 1.0) for c in cores)
+
+
+def test_workgroups_are_dealt_round_robin_to_the_xcds():
+    """The cluster sweep kernel places the workgroups of a bond group on one XCD by giving them block ids that are
+    congruent modulo 8 (ttx_cluster.h).  That is a performance assumption, not a correctness one (its barrier and
+    record exchange are agent-scope); this probe documents that it holds on the device under test."""
+    import ctypes
+    L = E.load_library()
+    L.ttx_k_xcc_map.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
+    out = np.zeros(64, dtype=np.int32)
+    assert L.ttx_k_xcc_map(0, 64, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == 0
+    assert out.min() >= 0 and out.max() <= 7
+    assert all(len(set(out[x::8])) == 1 for x in range(8)), out.tolist()
+
+
+def test_sweep_path_selection(monkeypatch):
+    s = D.ising_setup("c", 6, 33)
+    mk = lambda **kw: E.TTCross(s["n"], s["fun_id"], s["par"], 8, pivoting=2, accuracy=s["acc"], quad=s["quad"], **kw)
+    for want in ("chain", "fused", "cluster"):
+        monkeypatch.setenv("TTX_SWEEP", want)
+        assert mk().sweep_path() == want
+    monkeypatch.setenv("TTX_SWEEP", "auto")
+    assert mk().sweep_path() == "cluster"
+    sd = D.ising_setup("d", 6, 33)          # D/E and the exp integrands run on the multi-kernel chain
+    assert E.TTCross(sd["n"], sd["fun_id"], sd["par"], 8, pivoting=2).sweep_path() == "chain"
+    monkeypatch.setenv("TTX_SWEEP", "bogus")
+    with pytest.raises(E.TTXError, match="TTX_SWEEP"):
+        mk()

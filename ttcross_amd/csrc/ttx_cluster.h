@@ -3,18 +3,22 @@
 // The multi-kernel path pays six dependent launches per bond step and the single-workgroup kernel (ttx_fused.h)
 // pushes every fiber through one CU.  Here NB workgroups of 256 threads share a bond group and stay resident for
 // the whole sweep (lib/dmrgg.f90:329-760):
-//   * the blocks of a group are placed on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, so block ids
-//     g, g+8, g+16, ... share an L2): their barrier counter and the factor slabs they exchange stay in that L2;
+//   * the blocks of a group are placed on ONE XCD (workgroups are dealt round-robin to the 8 XCDs -- checked by
+//     ttx_k_xcc_map -- so block ids g, g+8, g+16, ... share an L2): what they exchange stays in that L2;
 //   * each block owns a slice of the mode index (j of the column fiber, k of the row fiber): it evaluates, keeps
 //     (LDS) and later appends exactly that slice, so fibers never travel between blocks;
-//   * the small serial parts (lottery draw and its arg-max, acceptance test) are computed redundantly and
-//     identically by every block, so the only cross-block traffic per rook half-step is one 32-byte partial
-//     arg-max record per block and one cluster barrier;
-//   * the barrier is a monotonic counter in global memory (agent-scope release/acquire).  Every spin is bounded:
-//     a block that waits too long raises the abort flag, all blocks leave, and the host reports the failure.
+//   * the small serial parts (lottery draw and its arg-max, acceptance test, pivot lists) are computed redundantly and
+//     identically by every block, so the only cross-block traffic per rook half-step is ONE tagged 32-byte record per
+//     block (its partial arg-max), written with one 16-byte store pair and polled with L1-bypassing loads -- no fence,
+//     no counter; once per bond step a counter barrier with release/acquire publishes the appended slabs;
+//   * everything that is fixed during a bond step is staged in LDS once: node/weight VALUES of both pivot sets, the
+//     prefix states of the integrand's two running sums per pivot row, the neighbour LU factors, the factor rows at
+//     the current pivot, and -- for the whole launch -- the sorted pivot lists of every own bond;
+//   * every wait is bounded: a block that waits too long raises the abort flag (pinned host memory), all blocks leave,
+//     and the host reports the failure instead of hanging the GPU.
 // All blocks of all groups must be resident at once: the host only takes this path when G*NB <= number of CUs.
 // Arithmetic and its order are identical to the other two paths (and to the oracle): same device functions, the
-// first-max rule is applied on global fiber positions.
+// first-max rule is applied on global fiber positions, reused partial results are bit-identical by construction.
 #pragma once
 #include "ttx_fused.h"
 
@@ -62,40 +66,28 @@ __device__ __forceinline__ u4 ld16(const void *p)
 __device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 15; }
 __global__ void k_xcc_probe(int *out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
 
-// barrier across the workgroups of one cluster; false: timed out / aborted (every thread gets the same answer).
-// mode 0: agent-scope release/acquire fences by every wave; mode 1: by one wave (cache maintenance acts on the CU's
-// L1 and the XCD's L2, not on a wave); mode 2: the cluster shares one XCD, so only the L1 is bypassed: stores are
-// complete in the common L2 after the workgroup-scope release, the counter is an L2 atomic, and the vector L1 is
-// invalidated before the block reads its partners' data.
-__device__ __forceinline__ bool cluster_sync(unsigned *ctr, unsigned target, int *abortflag, int *s_ok, int mode)
+// Barrier across the workgroups of one cluster with release/acquire semantics for ordinary global data; false: timed
+// out / aborted (every thread of the block gets the same answer).  Every wave first waits for its own stores to be
+// acknowledged by the L2; after the block barrier ONE wave performs the agent-scope release (L2 write-back), the
+// counter increment, the bounded spin and the agent-scope acquire: cache maintenance acts on the CU's L1 and the XCD's
+// L2, not on a wave, so repeating it per wave only multiplies its cost (measured: 12.0 -> 9.0 ms per C_64 run).
+__device__ __forceinline__ bool cluster_sync(unsigned *ctr, unsigned target, int *abortflag, int *s_ok)
 {
-    if (mode == 0) __threadfence();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are acknowledged by the L2
-    __syncthreads();                         // ... and so are those of every other wave of the block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         int ok = 1;
         unsigned spins = 0;
-        if (mode == 2) {
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            auto peek = [&]() { unsigned v; asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ctr) : "memory"); return v; };
-            while (peek() < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) { ok = 0; __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-            }
-            asm volatile("buffer_inv sc0" ::: "memory");
-        } else {
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) { ok = 0; __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-            }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);   // agent/system scope: drop stale L1/L2 lines
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) { ok = 0; __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if ((spins & 1023u) == 0 && __hip_atomic_load(abortflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { ok = 0; break; }
         }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
         *s_ok = ok;
     }
     __syncthreads();
-    if (mode == 0) __threadfence();
-    else if (mode == 2) asm volatile("buffer_inv sc0" ::: "memory");
     return *s_ok != 0;
 }
 
@@ -109,7 +101,7 @@ __device__ __forceinline__ bool cluster_sync(unsigned *ctr, unsigned target, int
 #define CST_END()
 #endif
 
-__global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int nsteps, int NB, int smode, int ldsinv, int epoch, int zkeep)
+__global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int nsteps, int NB, int ldsinv, int epoch, int zkeep)
 {
     extern __shared__ __align__(16) double dyn[];
     __shared__ int zc[128], zr[128], zcs[128], zrs[128], keepc[128], keepr[128];
@@ -577,7 +569,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         CST(14);
         // end of the bond step: appends and the new rank become visible to the whole cluster (every block read r[] of
         // this step before its first half-step barrier, so block 0 may already have overwritten r[p])
-        if (!cluster_sync(ctr, (++nbar) * (unsigned)NB, P.cl_abort, &s_ok, smode)) return;
+        if (!cluster_sync(ctr, (++nbar) * (unsigned)NB, P.cl_abort, &s_ok)) return;
         CST(15);
         CST_END();
     }

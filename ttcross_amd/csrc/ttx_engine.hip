@@ -656,7 +656,7 @@ static int run_impl(ttx_engine *h)
         if (h->cluster) {
             KScope ks(h, TTX_K_HALFSTEP, 1);
             hipLaunchKernelGGL(k_sweep_cluster, dim3(8 * h->cluster * ((G + 7) / 8)), dim3(CB), h->lds_cluster, st, P, dir, h->nbmax, h->cluster,
-                               getenv("TTX_CLUSTER_SYNC") ? atoi(getenv("TTX_CLUSTER_SYNC")) : 1, h->cluster_ldsinv, it_, h->cluster_zkeep);
+                               h->cluster_ldsinv, it_, h->cluster_zkeep);
         } else if (h->fused) {
             KScope ks(h, TTX_K_HALFSTEP, 1);
             hipLaunchKernelGGL(k_sweep_fused, dim3(G), dim3(FB), h->lds_fused, st, P, dir, h->nbmax);
@@ -1287,6 +1287,7 @@ extern "C" int ttx_ijk(ttx_engine *h, const int32_t *ind, double *val)
     return TTX_OK;
 }
 
+extern "C" int ttx_sweep_path(const ttx_engine *h) { return !h ? -1 : h->cluster ? 2 : h->fused ? 1 : 0; }
 extern "C" int ttx_set_profile(ttx_engine *h, int on) { if (!h) return fail(TTX_EINVAL, "null"); h->profile = on != 0; return TTX_OK; }
 extern "C" int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double ms[TTX_K_NKINDS], double bytes[TTX_K_NKINDS])
 {

@@ -267,6 +267,12 @@ class TTCross:
         tr = _Transport(None, self._cb[0], self._cb[1])
         _check(load_library().ttx_set_transport(self._h, ctypes.byref(tr)))
 
+    def sweep_path(self):
+        """'chain', 'fused' or 'cluster': the sweep implementation chosen at creation (TTX_SWEEP)."""
+        L = load_library()
+        L.ttx_sweep_path.argtypes = [c_void_p]
+        return ("chain", "fused", "cluster")[L.ttx_sweep_path(self._h)]
+
     def set_profile(self, on=True):
         _check(load_library().ttx_set_profile(self._h, 1 if on else 0))
 
