@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c64", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-extras", action="store_true", help="skip the k2_streaming and single_group side measurements (profiler runs: only the workload's own launches)")
     ap.add_argument("--groups", type=int, default=0, help="bond groups = MPI ranks of the reference's domain split; default 8 (config 3 of BASELINE.json) at every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (gloo: rehearsal with several ranks on one GPU)")
@@ -193,7 +194,7 @@ def main():
     # latency, is the limit.  And the reference's 1-rank decomposition (1 bond group) for comparison.
     k2 = None
     one_group = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_extras:
         m_rows, r_cols = 1 << 22, 32
         ms, by = E.k_residual_bench(m_rows, r_cols, 20, device=local)
         k2 = {"kernel": "k_resid_argmax_stream (K2 residual + arg-max, same arithmetic)", "rows": m_rows, "rank": r_cols,
