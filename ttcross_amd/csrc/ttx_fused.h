@@ -52,7 +52,7 @@ __global__ __launch_bounds__(FB) void k_sweep_fused(DevProb P, int dir, int nste
 {
     extern __shared__ __align__(16) double dyn[];
     __shared__ int zc[128], zr[128], zcs[128], zrs[128], keepc[128], keepr[128];
-    __shared__ int nzc, nzr, nsc, nsr, s_upd;
+    __shared__ int nzc, nzr, nsc, nsr;
     __shared__ ttx_cdfseg segc[TTX_TABSEG], segr[TTX_TABSEG];
     __shared__ double sha[16], shv[16]; __shared__ int shi[16];
     __shared__ unsigned long long sA[2];

@@ -748,7 +748,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     const bool iscol = (mode == 3) ? true : (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
     const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
     const int nf = iscol ? r0 * n1 : n2 * r2;
-    if (blockIdx.x * TTX_BLK >= nf) return;
+    if ((int)(blockIdx.x * TTX_BLK) >= nf) return;
     // LDS: par | xs[RM] | then either VALUE rows (Ising C when they fit: node and weight doubles, one 16-byte
     // aligned row per varying index + one fixed row) or INDEX rows (short) for the generic integrands
     const int VS = ((m + 7) & ~7) + 8;
