@@ -477,3 +477,24 @@ def test_sweep_path_selection(monkeypatch):
     monkeypatch.setenv("TTX_SWEEP", "bogus")
     with pytest.raises(E.TTXError, match="TTX_SWEEP"):
         mk()
+
+
+SHAPES = [(21, 17, 33, 3, 3), (9, 33, 48, 0, 2), (18, 3, 40, 0, 2), (15, 2, 3, 1, 1), (6, 9, 48, 1, 4), (4, 2, 6, 3, 2),
+          (13, 40, 40, 2, 3), (5, 7, 48, 3, 1), (19, 2, 33, 2, 1), (12, 40, 48, 3, 3), (20, 9, 40, 1, 4), (4, 33, 33, 2, 1)]
+
+
+@pytest.mark.parametrize("m,n,r,piv,ng", SHAPES, ids=[f"C{c[0]}_n{c[1]}_r{c[2]}_p{c[3]}_g{c[4]}" for c in SHAPES])
+def test_cluster_kernel_odd_shapes_bit_exact(m, n, r, piv, ng):
+    """The default (cluster) sweep kernel on shapes that stress its slicing: fewer mode indices than workgroups of a
+    cluster, ranks above 32 (one triangular solve per wave instead of two), tiny ranks, 1-4 bond groups, every pivoting
+    mode -- tapes, per-sweep values, evaluation counts, integral and finalised cores identical to the oracle."""
+    s = D.ising_setup("c", m, n)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng)
+    assert tt.sweep_path() == "cluster"
+    tt.run()
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng)
+    assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d])
+    assert [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]]
+    assert [a["neval"] for a in tt.sweeps()] == [b["neval"] for b in oo["sweeps"]]
+    assert tt.quad(s["quad"]) == oo["value"]
+    assert all(np.array_equal(tt.core(k), oo["cores"][k - 1]) for k in range(1, tt.d + 1))
