@@ -82,6 +82,7 @@ struct DevProb {
     const int *n;              // [d+2], 1-based
     const double *par;
     const double *aux;
+    const double *auxT;        // mvn: inv_cov transposed, auxT[j + d*i] = inv_cov(i,j) (same values, row walk contiguous)
     const double *quadw;       // [d+1][NM] padded, 1-based core index
     double *arg, *col, *row;   // [G][NC][CS]
     double *inv;               // [G][NC][RM*RM]   local bond bL = s - (first-1)

@@ -107,7 +107,7 @@ struct ttx_engine {
     double *Wa = nullptr, *Wb = nullptr, *Wc = nullptr, *Wd = nullptr, *Sm = nullptr, *bak = nullptr;
     int *Si = nullptr;
     size_t lds_half = 0, lds_lot = 0, lds_par = 0;
-    int half_vals = 0;
+    int half_vals = 0, lot_vals = 0;
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
     hipStream_t qstream = nullptr;      // forked per-sweep quadrature (single-process runs)
@@ -228,6 +228,14 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         HIPCHECK(hipMemcpy(dq, h->quadw.data(), sizeof(double) * h->quadw.size(), hipMemcpyHostToDevice));
     }
     P.n = dn; P.par = dpar; P.aux = daux; P.quadw = dq;
+    if (cfg->fun_id == TTX_FUN_MVN) {
+        std::vector<double> t((size_t)d * d);
+        for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) t[j + (size_t)d * i] = h->aux[d + i + (size_t)d * j];
+        double *dt;
+        A_(dev_alloc(h, &dt, t.size()));
+        HIPCHECK(hipMemcpy(dt, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+        P.auxT = dt;
+    }
     A_(dev_alloc(h, &P.arg, G * NC * P.CS)); A_(dev_alloc(h, &P.col, G * NC * P.CS)); A_(dev_alloc(h, &P.row, G * NC * P.CS));
     A_(dev_alloc(h, &P.inv, G * NC * RM * RM)); A_(dev_alloc(h, &P.vip, G * NC * 4 * RM));
     A_(dev_alloc(h, &P.L, G * NC * d * RM)); A_(dev_alloc(h, &P.R, G * NC * d * RM));
@@ -305,11 +313,15 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         const size_t idx_bytes = sizeof(short) * ((RM + 1) * VS + 16), val_bytes = sizeof(double) * ((RM + 1) * 2 * VS + 4);
         h->half_vals = (cfg->fun_id == TTX_FUN_ISING && P.ising_id == 1 && base + val_bytes <= 100 * 1024) ? 1 : 0;
         h->lds_half = base + (h->half_vals ? val_bytes : idx_bytes);
+        const size_t dif_bytes = sizeof(double) * ((RM + 1) * VS + 4);          // mvn: rows of differences x - mu
+        if (cfg->fun_id == TTX_FUN_MVN && base + dif_bytes <= 140 * 1024) { h->half_vals = 1; h->lds_half = base + dif_bytes; }
     }
     {
         const int nlotmax = 2 * h->RM + 2 * NM;
         const size_t VS = ((d + 7) & ~7) + 8;
         h->lds_lot = sizeof(double) * (cfg->npar + 4) + sizeof(int) * 4 * (nlotmax + 4) + sizeof(short) * (2 * RM * VS + 16);
+        const size_t lot_dif = sizeof(double) * (cfg->npar + 4) + sizeof(int) * 4 * (nlotmax + 4) + sizeof(double) * (2 * RM * VS + 4);
+        if (cfg->fun_id == TTX_FUN_MVN && lot_dif <= 120 * 1024) { h->lot_vals = 1; h->lds_lot = lot_dif; }
     }
     {   // whole-sweep kernels (Ising C): TTX_SWEEP = auto | chain | fused | cluster
         const size_t VS = ((d + 7) & ~7) + 8;
@@ -663,7 +675,7 @@ static int run_impl(ttx_engine *h)
         }
         for (int pp = 1; pp <= h->nbmax && !h->fused && !h->cluster; pp++) {
             if (h->cfg.pivoting >= 0) {
-                { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp); }
+                { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals); }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
                 for (int hh = 0; hh < h->H; hh++)
                     hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode, h->half_vals);

@@ -94,6 +94,36 @@ __device__ __forceinline__ double f_mvn(int m, const double *par, const double *
     return exp(-0.5 * ex) / norm;
 }
 
+// The same quadratic form from rows of DIFFERENCES x - mu staged in LDS: dims 1..A from da, dim A+1 = d1, (NS == 2:
+// dim A+2 = d2,) the remaining nb dims from db.  Term order and association are those of f_mvn / mvn_pdf
+// (lib/mvn_pdf.f90:74-80): ex = ex + (diff(i) * inv_cov(i,j)) * diff(j), i outer, j inner -- only the O(d) index
+// decoding per term is gone (the inverse covariance is read with wave-uniform addresses).
+template <int NS, class FN>
+__device__ __forceinline__ void mvn_dims(const double *da, int A, double d1, double d2, const double *db, int nb, FN fn)
+{
+#pragma unroll 8
+    for (int t = 0; t < A; t++) fn(da[t]);
+    fn(d1);
+    if (NS == 2) fn(d2);
+#pragma unroll 8
+    for (int t = 0; t < nb; t++) fn(db[t]);
+}
+template <int NS>
+__device__ __forceinline__ double f_mvn_rows(int m, const double *icT, double norm, const double *da, int A, double d1, double d2,
+                                             const double *db)
+{
+    const int nb = m - A - NS;
+    double ex = 0.0;
+    int i = 0;
+    mvn_dims<NS>(da, A, d1, d2, db, nb, [&](double di) {
+        const double *row = icT + (size_t)m * i;       // icT[j + m*i] = inv_cov(i,j): the j loop walks contiguous memory
+        int j = 0;
+        mvn_dims<NS>(da, A, d1, d2, db, nb, [&](double dj) { ex = ex + di * row[j] * dj; j++; });
+        i++;
+    });
+    return exp(-0.5 * ex) / norm;
+}
+
 template <int FUN, class IDX>
 __device__ __forceinline__ double eval_fun(const DevProb &P, const double *par, IDX idx)
 {
@@ -611,7 +641,7 @@ __global__ __launch_bounds__(256) void k_full_resolve(DevProb P)
 // one block per group
 // ------------------------------------------------------------------------------------------------
 template <int FUN>
-__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
+__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int vals)
 {
     extern __shared__ __align__(16) double dyn[];
     __shared__ StepState st;
@@ -638,8 +668,18 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
     const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
     const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
     for (int x = tid; x < P.npar; x += blockDim.x) par[x] = P.par[x];
+    // mvn: rows of differences x - mu (doubles) take the place of the index rows (host sized the LDS for them: vals)
+    const bool usem = (FUN == FUN_MVN) && (vals != 0);
+    double *DLv = (double *)(((size_t)LT + 15) & ~(size_t)15), *DRv = DLv + (size_t)r0 * VS;
+    if (usem) {
+        __syncthreads();
+        const double *mu = P.aux;
+        for (int x = tid; x < r0 * VS; x += blockDim.x) { const int c = x / VS, o = x - c * VS; DLv[x] = (o < p - 1) ? par[Lt[(size_t)o * P.RM + c] - 1] - mu[o] : 0.0; }
+        for (int x = tid; x < r2 * VS; x += blockDim.x) { const int c = x / VS, o = x - c * VS; DRv[x] = (o < m - p - 1) ? par[Rt[(size_t)o * P.RM + c] - 1] - mu[p + 1 + o] : 0.0; }
+    } else {
     for (int x = tid; x < r0 * VS; x += blockDim.x) { const int c = x / VS, o = x - c * VS; LT[x] = (o < p - 1) ? Lt[(size_t)o * P.RM + c] : (short)1; }
     for (int x = tid; x < r2 * VS; x += blockDim.x) { const int c = x / VS, o = x - c * VS; RT[x] = (o < m - p - 1) ? Rt[(size_t)o * P.RM + c] : (short)1; }
+    }
     // rnd.f90:120: d(nlot,2) column-major from the (never seeded) run-time generator.  Draw #k comes from the
     // generator word 48271^(2k+1): split as [48271^(2 pos+1)] * [48271^2]^il so that the long jump-ahead is done
     // once per block (threads 32/33) while every thread raises the short power
@@ -695,8 +735,13 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp)
         const int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
         const int i = (x - 1) % r0 + 1, j = (x - 1) / r0 + 1, k = (y - 1) % n2 + 1, q = (y - 1) / n2 + 1;   // :447-452
         lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
-        Src4 sx{LT + (size_t)(i - 1) * VS, p - 1, j, k, RT + (size_t)(q - 1) * VS};
-        const double f = eval_src4<FUN>(P, par, sx);                               // :455-463
+        double f;
+        if (usem) f = f_mvn_rows<2>(m, P.auxT, P.mvn_norm, DLv + (size_t)(i - 1) * VS, p - 1, par[j - 1] - P.aux[p - 1], par[k - 1] - P.aux[p],
+                                    DRv + (size_t)(q - 1) * VS);
+        else {
+            Src4 sx{LT + (size_t)(i - 1) * VS, p - 1, j, k, RT + (size_t)(q - 1) * VS};
+            f = eval_src4<FUN>(P, par, sx);                                        // :455-463
+        }
         ma = fmax(ma, fabs(f));
         const double *c = Cp + (i - 1) + (size_t)P.RM * (j - 1), *w = Wq + (k - 1) + (size_t)P.NM * (q - 1);
         double t = 0.0;                                                            // ddot, :474
@@ -778,9 +823,23 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             fn[x] = par[ix - 1]; fw[x] = par[n1m + ix - 1];
         }
     }
+    const bool usem = (FUN == FUN_MVN) && (vals != 0);      // rows of differences x - mu (doubles): [vcols][VS] + fixed row
+    if (usem) {
+        const double *mu = P.aux;
+        double *df = vbase + (size_t)vcols * VS;
+        if (iscol) {
+            for (int x = tid; x < vcols * VS; x += TTX_BLK) { const int c = x / VS, o = x % VS; vbase[x] = (o < vrows) ? par[Lt[(size_t)o * P.RM + c] - 1] - mu[o] : 0.0; }
+            for (int x = tid; x < VS; x += TTX_BLK)
+                df[x] = (x == 0) ? par[cur.kk - 1] - mu[p] : (x < m - p) ? par[Rt[(size_t)(x - 1) * P.RM + (cur.qq - 1)] - 1] - mu[p + x] : 0.0;
+        } else {
+            for (int x = tid; x < vcols * VS; x += TTX_BLK) { const int c = x / VS, o = x % VS; vbase[x] = (o < vrows) ? par[Rt[(size_t)o * P.RM + c] - 1] - mu[p + 1 + o] : 0.0; }
+            for (int x = tid; x < VS; x += TTX_BLK)
+                df[x] = (x < p - 1) ? par[Lt[(size_t)x * P.RM + (cur.ii - 1)] - 1] - mu[x] : (x == p - 1) ? par[cur.jj - 1] - mu[p - 1] : 0.0;
+        }
+    }
     short *fxs = (short *)vbase;
     short *vt = fxs + VS;
-    if (!usev) {
+    if (!usev && !usem) {
         if (iscol) {   // varying: left pivot i (dims 1..p-1) and j; fixed: kk and the right multi-index of qq (dims p+1..m)
             for (int x = tid; x < vcols * VS; x += TTX_BLK) { const int c = x / VS, o = x % VS; vt[x] = (o < vrows) ? Lt[(size_t)o * P.RM + c] : (short)1; }
             for (int x = tid; x < VS; x += TTX_BLK) fxs[x] = (x == 0) ? (short)cur.kk : (x < m - p) ? Rt[(size_t)(x - 1) * P.RM + (cur.qq - 1)] : (short)1;
@@ -803,6 +862,10 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             const double *fn = vbase + (size_t)vcols * 2 * VS, *fw = fn + VS;
             if (iscol) { const double *rn = vbase + (size_t)u * 2 * VS; a = f_ising_c3v(m, p - 1, rn, rn + VS, par[v], par[n1m + v], fn, fw); }
             else       { const double *rn = vbase + (size_t)v * 2 * VS; a = f_ising_c3v(m, p, fn, fw, par[u], par[n1m + u], rn, rn + VS); }
+        } else if (usem) {
+            const double *mu = P.aux, *df = vbase + (size_t)vcols * VS;
+            if (iscol) a = f_mvn_rows<1>(m, P.auxT, P.mvn_norm, vbase + (size_t)u * VS, p - 1, par[v] - mu[p - 1], 0.0, df);
+            else       a = f_mvn_rows<1>(m, P.auxT, P.mvn_norm, df, p, par[u] - mu[p], 0.0, vbase + (size_t)v * VS);
         } else {
             Src3 sx;
             if (iscol) { sx.pa = vt + (size_t)u * VS; sx.A = p - 1; sx.self = v + 1; sx.pb = fxs; }
