@@ -82,6 +82,8 @@ struct DevProb {
     const int *n;              // [d+2], 1-based
     const double *par;
     const double *aux;
+    double *deTL, *deUL, *deTR;  // Ising D/E: per-bond pair-factor tables [G][de_npair][RM], [G][d+1][RM], [G][de_npair][RM] (k_de_tables)
+    int de_npair;
     const double *auxT;        // mvn: inv_cov transposed, auxT[j + d*i] = inv_cov(i,j) (same values, row walk contiguous)
     const double *quadw;       // [d+1][NM] padded, 1-based core index
     double *arg, *col, *row;   // [G][NC][CS]

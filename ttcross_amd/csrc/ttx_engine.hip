@@ -228,6 +228,11 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         HIPCHECK(hipMemcpy(dq, h->quadw.data(), sizeof(double) * h->quadw.size(), hipMemcpyHostToDevice));
     }
     P.n = dn; P.par = dpar; P.aux = daux; P.quadw = dq;
+    if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && !(getenv("TTX_DE_TABLES") && atoi(getenv("TTX_DE_TABLES")) == 0)) {
+        P.de_npair = d * (d + 1) / 2;
+        A_(dev_alloc(h, &P.deTL, G * (size_t)P.de_npair * RM)); A_(dev_alloc(h, &P.deTR, G * (size_t)P.de_npair * RM));
+        A_(dev_alloc(h, &P.deUL, G * (size_t)(d + 1) * RM));
+    }
     if (cfg->fun_id == TTX_FUN_MVN) {
         std::vector<double> t((size_t)d * d);
         for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) t[j + (size_t)d * i] = h->aux[d + i + (size_t)d * j];
@@ -674,6 +679,10 @@ static int run_impl(ttx_engine *h)
             hipLaunchKernelGGL(k_sweep_fused, dim3(G), dim3(FB), h->lds_fused, st, P, dir, h->nbmax);
         }
         for (int pp = 1; pp <= h->nbmax && !h->fused && !h->cluster; pp++) {
+            if (P.deTL) {   // Ising D/E: pair factors of this bond that do not span it (shared by all elements through a pivot)
+                KScope ks(h, TTX_K_OTHER);
+                hipLaunchKernelGGL(k_de_tables, dim3((2 * (d + 1) * h->RM + 255) / 256, G), dim3(256), 0, st, P, dir, pp);
+            }
             if (h->cfg.pivoting >= 0) {
                 { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals); }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);

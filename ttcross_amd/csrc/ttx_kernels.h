@@ -220,12 +220,50 @@ __device__ __forceinline__ void dims_asc(const short *pa, int A, int s1, int s2,
     const int b0 = jlo > A + NS + 1 ? jlo : A + NS + 1;
     if (b0 <= jhi) seg_range(pb, b0 - A - NS - 1, jhi - A - NS, tab, step);
 }
+// b-part (id 2) and the weights of the D / E integrand once the pair product a is known (:197-218)
+template <int NS>
+__device__ __forceinline__ double de_finish(int id, double a, int m, int n1, const double *par, const short *pa, int A, int s1, int s2, const short *pb);
+
+// Pair product of an element (left pivot row il | s1 | s2 | right pivot row q) from the per-bond tables built by
+// k_de_tables: the factor ((u_ij-1)/(u_ij+1))^2 of a pair depends only on the dims i+1..j, so every pair that lies
+// entirely in the left pivot's dims (TL) or entirely in the right pivot's dims (TR) is shared by all elements through
+// that pivot and is only MULTIPLIED here -- in the reference's order, so the product is bit-identical; the IEEE
+// divisions are left for the pairs that span the bond (about a third of all pairs on average).
+// TLc / ULc / TRc point at the pivot's column of the [pair][RM] tables; rix[ro .. ro+B): the right pivot's index entries
+// (rix itself 16-byte aligned and padded).
+__device__ __forceinline__ double de_pairs_tab(int m, const double *nodes, int A, const double *TLc, const double *ULc, int RM,
+                                               int s1, int s2, const short *rix, int ro, const double *TRc)
+{
+    const int B = m - A - 2;
+    const double x1 = nodes[s1], x2 = nodes[s2];
+    double a = 1.0;
+    size_t pr = 0;
+    auto run = [&](double u) {                          // the bond-spanning tail of a row: ... s2, right dims
+        auto step = [&](double xv) { u = u * xv; const double t = (u - 1.0) / (u + 1.0); a = a * (t * t); };
+        step(x2);
+        seg_range(rix, ro, ro + B, nodes, step);
+    };
+    for (int i = 0; i <= A; i++) {
+        const int cnt = A - i;
+#pragma unroll 8
+        for (int t = 0; t < cnt; t++) a = a * TLc[(pr + t) * RM];
+        pr += cnt;
+        double u = ULc[(size_t)i * RM];
+        u = u * x1; { const double t = (u - 1.0) / (u + 1.0); a = a * (t * t); }
+        run(u);
+    }
+    run(1.0);                                           // i = A+1: starts after s1
+    const size_t nr = (size_t)B * (B + 1) / 2;          // i >= A+2: pairs inside the right pivot's dims
+#pragma unroll 8
+    for (size_t t = 0; t < nr; t++) a = a * TRc[t * RM];
+    return a;
+}
+
 template <int NS>
 __device__ __forceinline__ double f_ising_de(int id, int m, int n1, const double *par, const short *pa, int A, int s1, int s2, const short *pb)
 {
-    const double *nodes = par - 1, *weights = par + n1 - 1;
-    const int nb = m - A - NS;
-    double a = 1.0, b = 0.0;
+    const double *nodes = par - 1;
+    double a = 1.0;
     for (int i = 0; i <= m; i++) {                                   // :186-195
         double uij = 1.0;
         const int jlo = i + 1, jhi = m;
@@ -236,6 +274,14 @@ __device__ __forceinline__ double f_ising_de(int id, int m, int n1, const double
             a = a * (t * t);
         });
     }
+    return de_finish<NS>(id, a, m, n1, par, pa, A, s1, s2, pb);
+}
+template <int NS>
+__device__ __forceinline__ double de_finish(int id, double a, int m, int n1, const double *par, const short *pa, int A, int s1, int s2, const short *pb)
+{
+    const double *nodes = par - 1, *weights = par + n1 - 1;
+    const int nb = m - A - NS;
+    double b = 0.0;
     if (id == 2) {                                                   // :197-205
         double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
         auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
@@ -636,6 +682,50 @@ __global__ __launch_bounds__(256) void k_full_resolve(DevProb P)
     }
 }
 
+// Ising D / E: per-bond tables of the pair factors that do not span the bond (see de_pairs_tab).  For every left
+// pivot c of bond p-1 (dims 1..A, A = p-1) and every start i: TL[(off(i) + j-i-1)*RM + c] = ((u-1)/(u+1))^2 with
+// u = x_{i+1}*...*x_j accumulated left to right (test_crs_ising.f90:188-192), UL[i*RM + c] = u after j = A; the same
+// for every right pivot of bond p+1 over its own dims (TR).  One thread per (start, pivot); pivot index fastest, so
+// the tables are written -- and later read by a column fiber -- coalesced.
+__global__ __launch_bounds__(256) void k_de_tables(DevProb P, int dir, int pp)
+{
+    const int g = blockIdx.y, m = P.d, RM = P.RM;
+    const GroupState &gs = P.gs[g];
+    const int first = gs.first, last = gs.last;
+    if (pp > last - first + 1) return;
+    const int p = (dir == 1) ? first + pp - 1 : last + 1 - pp;
+    const int *r = P.r + (size_t)g * (m + 2);
+    const int r0 = r[p - 1], r2 = r[p + 1], A = p - 1, B = m - p - 1;
+    const double *nodes = P.par - 1;
+    const size_t tsz = (size_t)P.de_npair * RM;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = x % RM, i = (x / RM) % (m + 1), side = x / (RM * (m + 1));
+    if (side == 0) {
+        if (c >= r0 || i > A) return;
+        const short *Lt = L_ptr(P, g, p - 1, first);
+        double *TL = P.deTL + (size_t)g * tsz, *UL = P.deUL + (size_t)g * (m + 1) * RM;
+        const size_t off = (size_t)i * A - (size_t)i * (i - 1) / 2;
+        double u = 1.0;
+        for (int j = i + 1; j <= A; j++) {
+            u = u * nodes[Lt[(size_t)(j - 1) * RM + c]];
+            const double t = (u - 1.0) / (u + 1.0);
+            TL[(off + (j - i - 1)) * RM + c] = t * t;
+        }
+        UL[(size_t)i * RM + c] = u;
+    } else if (side == 1) {
+        if (c >= r2 || i >= B) return;
+        const short *Rt = R_ptr(P, g, p + 1, first);
+        double *TR = P.deTR + (size_t)g * tsz;
+        const size_t off = (size_t)i * B - (size_t)i * (i - 1) / 2;
+        double u = 1.0;
+        for (int j = i + 1; j <= B; j++) {
+            u = u * nodes[Rt[(size_t)(j - 1) * RM + c]];
+            const double t = (u - 1.0) / (u + 1.0);
+            TR[(off + (j - i - 1)) * RM + c] = t * t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_lottery: lottery2 candidates, their values and residuals, start pivot (lib/dmrgg.f90:410-484)
 // one block per group
@@ -738,7 +828,13 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         double f;
         if (usem) f = f_mvn_rows<2>(m, P.auxT, P.mvn_norm, DLv + (size_t)(i - 1) * VS, p - 1, par[j - 1] - P.aux[p - 1], par[k - 1] - P.aux[p],
                                     DRv + (size_t)(q - 1) * VS);
-        else {
+        else if (FUN == FUN_ISING && P.ising_id != 1 && P.deTL) {
+            const size_t tsz = (size_t)P.de_npair * P.RM;
+            const double *TL = P.deTL + (size_t)g * tsz, *UL = P.deUL + (size_t)g * (m + 1) * P.RM, *TR = P.deTR + (size_t)g * tsz;
+            const short *pa_ = LT + (size_t)(i - 1) * VS, *pb_ = RT + (size_t)(q - 1) * VS;
+            const double ap = de_pairs_tab(m, par - 1, p - 1, TL + (i - 1), UL + (i - 1), P.RM, j, k, pb_, 0, TR + (q - 1));
+            f = de_finish<2>(P.ising_id, ap, m, P.n[1], par, pa_, p - 1, j, k, pb_);
+        } else {
             Src4 sx{LT + (size_t)(i - 1) * VS, p - 1, j, k, RT + (size_t)(q - 1) * VS};
             f = eval_src4<FUN>(P, par, sx);                                        // :455-463
         }
@@ -862,6 +958,17 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             const double *fn = vbase + (size_t)vcols * 2 * VS, *fw = fn + VS;
             if (iscol) { const double *rn = vbase + (size_t)u * 2 * VS; a = f_ising_c3v(m, p - 1, rn, rn + VS, par[v], par[n1m + v], fn, fw); }
             else       { const double *rn = vbase + (size_t)v * 2 * VS; a = f_ising_c3v(m, p, fn, fw, par[u], par[n1m + u], rn, rn + VS); }
+        } else if (FUN == FUN_ISING && P.ising_id != 1 && P.deTL) {
+            const size_t tsz = (size_t)P.de_npair * P.RM;
+            const double *TL = P.deTL + (size_t)g * tsz, *UL = P.deUL + (size_t)g * (m + 1) * P.RM, *TR = P.deTR + (size_t)g * tsz;
+            double pa_;
+            if (iscol) {     // left pivot u varies, s1 = v+1, s2 = kk, right pivot qq fixed (fxs = [kk, right dims])
+                pa_ = de_pairs_tab(m, par - 1, p - 1, TL + u, UL + u, P.RM, v + 1, cur.kk, fxs, 1, TR + (cur.qq - 1));
+                a = de_finish<1>(P.ising_id, pa_, m, n1m, par, vt + (size_t)u * VS, p - 1, v + 1, 0, fxs);
+            } else {         // left pivot ii fixed (fxs = [left dims, jj]), s1 = jj, s2 = u+1, right pivot v varies
+                pa_ = de_pairs_tab(m, par - 1, p - 1, TL + (cur.ii - 1), UL + (cur.ii - 1), P.RM, cur.jj, u + 1, vt + (size_t)v * VS, 0, TR + v);
+                a = de_finish<1>(P.ising_id, pa_, m, n1m, par, fxs, p, u + 1, 0, vt + (size_t)v * VS);
+            }
         } else if (usem) {
             const double *mu = P.aux, *df = vbase + (size_t)vcols * VS;
             if (iscol) a = f_mvn_rows<1>(m, P.auxT, P.mvn_norm, vbase + (size_t)u * VS, p - 1, par[v] - mu[p - 1], 0.0, df);
