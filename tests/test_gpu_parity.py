@@ -498,3 +498,23 @@ def test_cluster_kernel_odd_shapes_bit_exact(m, n, r, piv, ng):
     assert [a["neval"] for a in tt.sweeps()] == [b["neval"] for b in oo["sweeps"]]
     assert tt.quad(s["quad"]) == oo["value"]
     assert all(np.array_equal(tt.core(k), oo["cores"][k - 1]) for k in range(1, tt.d + 1))
+
+
+def test_chf_driver_against_oracle():
+    """The caller on the far side of the path: test_crs_chf.f90's pipeline -- cross of the mvn density
+    without quad, then the 32 complex quadratures -- through ttcross_amd.drivers.run_chf.  Checked against the oracle:
+    ztt_quad of the SAME device train (1e-13), and the oracle's own cross + ztt_quad (exp-based integrand: 1e-9 of the
+    k = 0 value, which is the plain integral)."""
+    tt, vals, s = D.run_chf(["4", "17", "8", "2"], verbose=False)
+    n, d = s["n"][0], len(s["n"])
+    W = D.chf_weights(s["par"], n, d)
+    ot = O.OracleTT([tt.core(k) for k in range(1, d + 1)])
+    for k in range(32):
+        want = ot.zquad(W[k])
+        assert abs(vals[k] - want) <= 1e-13 * abs(want) + 1e-300
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], 8, piv=2, accuracy=s["acc"], aux=s["aux"])
+    oref = O.OracleTT(oo["cores"])
+    scale = abs(oref.zquad(W[0]))
+    assert abs(vals[0].imag) <= 1e-12 * scale                  # omega = 0: real weights
+    for k in range(32):
+        assert abs(vals[k] - oref.zquad(W[k])) <= 1e-9 * scale

@@ -118,5 +118,33 @@ def run_driver(argv, device=0, verbose=True):
     return tt, val, s
 
 
+def chf_weights(par, n, d, nfreq=32, upper=300.0):
+    """The complex rank-1 quadrature weights of test_crs_chf.f90:153-168: for frequency k the weight of node p in every
+    mode is w(p) * exp(i * omega_k * exp(x(p)) / d), omega_k = k*pi/(upper - 0).  Returns an (nfreq, d*n) array."""
+    x, w = par[:n], par[n:2 * n]
+    return np.array([np.tile(w * np.exp(1j * (k * math.pi / upper) * np.exp(x) / d), d) for k in range(nfreq)])
+
+
+def run_chf(argv, device=0, verbose=True):
+    """test_crs_chf.f90:104-168: TT-cross of the multivariate-normal density WITHOUT a quadrature argument, then the
+    characteristic function of the basket average at 32 frequencies as complex rank-1 quadratures of the resident
+    train (ztt_quad, lib/dmrgg.f90:1418), all 32 in ONE batched device call."""
+    d, n, r, piv = int(argv[0]), int(argv[1]), int(argv[2]), int(argv[3])
+    ng = int(argv[4]) if len(argv) > 4 else 1
+    s = box_setup("mvn", d, n)
+    n = s["n"][0]
+    tt = TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], aux=s["aux"], nproc=ng, device=device, verbose=verbose)
+    tt.run()
+    vals = tt.zquad(chf_weights(s["par"], n, d))
+    if verbose:
+        print("...with%12d evaluations completed in %12.4E sec." % (tt.neval, tt.seconds))
+        for k, v in enumerate(vals):
+            print("computed value: %3d %.16e %.16e" % (k, v.real, v.imag))
+    return tt, vals, s
+
+
 if __name__ == "__main__":
-    run_driver(sys.argv[1:])
+    if sys.argv[1] == "chf":
+        run_chf(sys.argv[2:])
+    else:
+        run_driver(sys.argv[1:])
