@@ -30,6 +30,7 @@ WORKLOADS = {
     "c16": (("ising", "c", 16, 51, 32, 2), "Ising C_16 n=51 r=32 piv=2 (d=15)"),
     "d32": (("ising", "d", 32, 51, 24, 2), "Ising D_32 n=51 r=24 piv=2 (d=31)"),
 }
+FP64_VECTOR_PEAK_TFLOPS = 78.0      # MI355X fp64 vector (non-matrix) peak, SURVEY 8(d)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -246,6 +247,11 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "kernel_ms_per_step": {k: v["ms"] / max(1, min(a.steps, 3)) for k, v in agg.items()},
     }
+    # K1 (fiber evaluation) as fp64 vector work, SURVEY 8(d): algorithmic flops per evaluation of the integrand
+    dd = len(s["n"])
+    fl = (5 * dd + 1) if argv[1] == "c" else (6 * dd * (dd + 1) // 2 + 5 * dd)
+    out["k1_evaluation"] = {"flops_per_eval": fl, "achieved": (neval / dt) * fl / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": (neval / dt) * fl / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
     if k2:
         out["k2_streaming"] = k2
     if one_group:
