@@ -425,19 +425,52 @@ __device__ __forceinline__ double eval_src3(const DevProb &P, const double *par,
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ------------------------------------------------------------------------------------------------
+// Wave-wide reductions on the DPP data path (cross-lane operands of the VALU itself) instead of ds_bpermute round trips
+// through the LDS crossbar: butterfly inside each row of 16 lanes (quad_perm xor 1, xor 2, row_ror 4, row_ror 8), then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3; lane 63 holds the result, broadcast by readlane.
+// Both operations are idempotent, so lanes that a step does not address combine with their own value.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, ROWMASK, 0xf, false); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_d(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = dpp_i<CTRL, ROWMASK>((int)b), hi = dpp_i<CTRL, ROWMASK>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane63(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_max(double v)
 {
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmax(v, dpp_d<0xb1, 0xf>(v));
+    v = fmax(v, dpp_d<0x4e, 0xf>(v));
+    v = fmax(v, dpp_d<0x124, 0xf>(v));
+    v = fmax(v, dpp_d<0x128, 0xf>(v));
+    v = fmax(v, dpp_d<0x142, 0xa>(v));
+    v = fmax(v, dpp_d<0x143, 0xc>(v));
+    return readlane63(v);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void argmax_step(double &a, double &v, int &idx)
+{
+    // first-max rule of idamax: larger |.| wins, ties go to the lower index
+    const double a2 = dpp_d<CTRL, ROWMASK>(a), v2 = dpp_d<CTRL, ROWMASK>(v);
+    const int i2 = dpp_i<CTRL, ROWMASK>(idx);
+    if (a2 > a || (a2 == a && i2 < idx)) { a = a2; v = v2; idx = i2; }
 }
 __device__ __forceinline__ void wave_argmax(double &a, double &v, int &idx)
 {
-    // first-max rule of idamax: larger |.| wins, ties go to the lower index
-    for (int o = 32; o > 0; o >>= 1) {
-        double a2 = __shfl_xor(a, o, 64), v2 = __shfl_xor(v, o, 64);
-        int i2 = __shfl_xor(idx, o, 64);
-        if (a2 > a || (a2 == a && i2 < idx)) { a = a2; v = v2; idx = i2; }
-    }
+    argmax_step<0xb1, 0xf>(a, v, idx);
+    argmax_step<0x4e, 0xf>(a, v, idx);
+    argmax_step<0x124, 0xf>(a, v, idx);
+    argmax_step<0x128, 0xf>(a, v, idx);
+    argmax_step<0x142, 0xa>(a, v, idx);
+    argmax_step<0x143, 0xc>(a, v, idx);
+    a = readlane63(a); v = readlane63(v); idx = __builtin_amdgcn_readlane(idx, 63);
 }
 // returns block max to every thread; sh must hold blockDim/64 doubles
 __device__ __forceinline__ double block_max(double v, double *sh)
