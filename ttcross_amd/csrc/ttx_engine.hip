@@ -532,7 +532,7 @@ static void print_line(const ttx_engine *h, const ttx_sweep_rec &r, double val_p
 // job-wide summary of the sweep -> h->h_sum (one all-reduce, one stream synchronisation)
 static int readback(ttx_engine *h)
 {
-    hipLaunchKernelGGL(k_collect, dim3(1), dim3(64), 0, h->stream, h->P);
+    hipLaunchKernelGGL(k_collect, dim3(1), dim3(256), 0, h->stream, h->P);
     if (h->W > 1 && !h->comm) {
         // host-callback transport: reduce on the host copy directly
         if (!h->have_cb) return fail(TTX_ESTATE, "world_size > 1 but neither ttx_comm_init nor ttx_set_transport was called");

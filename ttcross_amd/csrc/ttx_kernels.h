@@ -1619,9 +1619,9 @@ __global__ __launch_bounds__(256) void k_quad_tree(DevProb P)
 
 // per-sweep summary of this GPU in the job-wide layout (slots of other GPUs stay zero; SUM all-reduce)
 __device__ __forceinline__ void collect_summary(const DevProb &P);
-__global__ void k_collect(DevProb P)
+__global__ __launch_bounds__(256) void k_collect(DevProb P)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || P.ctl[0]) return;
+    if (blockIdx.x != 0 || P.ctl[0]) return;
     collect_summary(P);
 }
 // single-GPU end of sweep in one launch: snapshot for the forked quadrature, summary (written straight into the
@@ -1655,19 +1655,23 @@ __global__ __launch_bounds__(256) void k_sweep_end(DevProb P, int it, double *ou
 }
 __device__ __forceinline__ void collect_summary(const DevProb &P)
 {
-    const int m = P.d;
+    const int m = P.d, tid = threadIdx.x;
     double *o = P.sumsend;
+    for (int g = 0; g < P.G; g++) {                                   // one thread per own bond of the group
+        const GroupState &gs = P.gs[g];
+        const int *r = P.r + (size_t)g * (m + 2), *tp = P.tape + (size_t)g * (m + 2) * 4;
+        for (int p = gs.first + tid; p <= gs.last; p += blockDim.x) {
+            double *e = o + SUM_HDR + P.nprocs + 5 * p;
+            e[0] = (double)r[p]; e[1] = (double)tp[4 * p]; e[2] = (double)tp[4 * p + 1]; e[3] = (double)tp[4 * p + 2]; e[4] = (double)tp[4 * p + 3];
+        }
+    }
+    if (tid != 0) return;
     double nev = 0.0, by = 0.0, nr = 0.0;
     for (int g = 0; g < P.G; g++) {
         const GroupState &gs = P.gs[g];
         nev += (double)gs.neval; by += gs.bytes_half; nr += (double)gs.n_resid;
         o[SUM_HDR + gs.gglobal] = gs.initval;
         if (gs.gglobal == 0) { o[SUM_AMAX] = gs.amax; o[SUM_PMAX] = gs.pivotmax; o[SUM_PMIN] = gs.pivotmin; }
-        const int *r = P.r + (size_t)g * (m + 2), *tp = P.tape + (size_t)g * (m + 2) * 4;
-        for (int p = gs.first; p <= gs.last; p++) {
-            double *e = o + SUM_HDR + P.nprocs + 5 * p;
-            e[0] = (double)r[p]; e[1] = (double)tp[4 * p]; e[2] = (double)tp[4 * p + 1]; e[3] = (double)tp[4 * p + 2]; e[4] = (double)tp[4 * p + 3];
-        }
     }
     o[SUM_NEVAL] = nev; o[SUM_BYTES] = by; o[SUM_NRESID] = nr;
     if (P.g0 == 0) o[SUM_VAL] = P.gs[0].val;     // identical on every GPU; contributed once
