@@ -1113,14 +1113,16 @@ static int ort_impl(ttx_engine *h)
     const int d = h->d, RM = h->RM; const size_t SS = h->P.SS;
     std::vector<int32_t> &r = h->rfinal;
     double *Rm = h->Sm, *tau = h->Sm + 8 * (size_t)RM * RM;
-    double lognrm = 0.0, s2; int rc;
+    double *acc = h->Sm + 8 * (size_t)RM * RM + 4 * RM + 2;             // device scalars: sum of log norms, last 1/norm
+    int rc;
+    HIPCHECK(hipMemsetAsync(acc, 0, 2 * sizeof(double), h->stream));
+    // the whole left-to-right pass is enqueued without a host round trip: the new ranks min(r0*n, r1) are known on the
+    // host, the norm equalisation (log of each R's norm, final rescaling) stays on the device
     for (int k = 1; k <= d - 1; k++) {                                  // lib/tt.f90:149-181
         const int r0 = r[k - 1], n = h->n1[k], r1 = r[k], mm = r0 * n, nn = r1, mn = std::min(mm, nn), kk = h->n1[k + 1] * r[k + 1];
         hipLaunchKernelGGL(k_pack_core, g1((size_t)mm * nn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, r0, n, r1, RM, SS, 0);
         if ((rc = qr(h, mm, nn, h->Wa, Rm, tau))) return rc;
-        if ((rc = sumsq(h, (size_t)mn * nn, Rm, &s2))) return rc;
-        const double nrm = std::sqrt(s2);
-        if (nrm != 0.0) { hipLaunchKernelGGL(k_scal, g1((size_t)mn * nn), dim3(256), 0, h->stream, (size_t)mn * nn, Rm, 1.0 / nrm); lognrm += std::log(nrm); }
+        hipLaunchKernelGGL(k_norm_log, dim3(1), dim3(1024), 0, h->stream, (size_t)mn * nn, Rm, acc, 1);
         hipLaunchKernelGGL(k_unpack_core, g1((size_t)mm * mn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, r0, n, mn, RM, SS, 0, 1.0);
         hipLaunchKernelGGL(k_pack_core, g1((size_t)nn * kk), dim3(256), 0, h->stream, core_dev(h, k + 1), h->Wb, nn, h->n1[k + 1], r[k + 1], RM, SS, 0);
         gemm(h, mn, kk, nn, Rm, mn, h->Wb, nn, h->Wc, mn);             // R pushed into the next core (:175), fp64 MFMA
@@ -1129,14 +1131,10 @@ static int ort_impl(ttx_engine *h)
     }
     const size_t last = (size_t)r[d - 1] * h->n1[d] * r[d];
     hipLaunchKernelGGL(k_pack_core, g1(last), dim3(256), 0, h->stream, core_dev(h, d), h->Wa, r[d - 1], h->n1[d], r[d], RM, SS, 0);
-    if ((rc = sumsq(h, last, h->Wa, &s2))) return rc;
-    double nl = std::sqrt(s2), lastscale = 1.0;
-    if (nl != 0.0) { lastscale = 1.0 / nl; lognrm += std::log(nl); }    // :184-188
-    lognrm /= d;
-    const double nrm = std::exp(lognrm);                                // :190-194
-    for (int k = 1; k <= d; k++)
-        hipLaunchKernelGGL(k_scal_core, g1((size_t)r[k - 1] * h->n1[k] * r[k]), dim3(256), 0, h->stream, core_dev(h, k), r[k - 1], h->n1[k], r[k], RM, SS,
-                           (k == d) ? nrm * lastscale : nrm);
+    hipLaunchKernelGGL(k_norm_log, dim3(1), dim3(1024), 0, h->stream, last, h->Wa, acc, 0);     // :184-188
+    for (int k = 1; k <= d; k++)                                        // :190-194
+        hipLaunchKernelGGL(k_scal_core_acc, g1((size_t)r[k - 1] * h->n1[k] * r[k]), dim3(256), 0, h->stream, core_dev(h, k), r[k - 1], h->n1[k], r[k], RM, SS,
+                           acc, d, (k == d) ? 1 : 0);
     push_ranks(h);
     HIPCHECK(hipGetLastError());
     return TTX_OK;

@@ -150,6 +150,34 @@ __global__ __launch_bounds__(1024) void k_sumsq(size_t n, const double *x, doubl
     p = tt_block_sum(p, red);
     if (threadIdx.x == 0) out[0] = p;
 }
+// norm equalisation of dtt_ort without a host round trip (lib/tt.f90:166-172, 184-188): nrm = ||x||_2; x *= 1/nrm;
+// acc[0] += log(nrm).  scale_x = 0: x is left alone and 1/nrm is kept in acc[1] (the last core, scaled at the end).
+__global__ __launch_bounds__(1024) void k_norm_log(size_t n, double *x, double *acc, int scale_x)
+{
+    __shared__ double red[16];
+    __shared__ double s_inv;
+    double p = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) p += x[i] * x[i];
+    p = tt_block_sum(p, red);
+    if (threadIdx.x == 0) {
+        const double nrm = sqrt(p);
+        s_inv = (nrm != 0.0) ? 1.0 / nrm : 1.0;
+        if (nrm != 0.0) acc[0] += log(nrm);
+        if (!scale_x) acc[1] = s_inv;
+    }
+    __syncthreads();
+    if (scale_x && s_inv != 1.0) for (size_t i = threadIdx.x; i < n; i += blockDim.x) x[i] *= s_inv;
+}
+// final rescaling of every core by exp(acc[0]/d) (times acc[1] for the core whose norm was only measured)
+__global__ void k_scal_core_acc(double *core, int r0, int n, int r1, int RM, size_t SS, const double *acc, int d, int extra)
+{
+    const double a = exp(acc[0] / d) * (extra ? acc[1] : 1.0);
+    const size_t tot = (size_t)r0 * n * r1;
+    for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < tot; x += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(x % r0); size_t c = x / r0; int j = (int)(c % n), s = (int)(c / n);
+        core[i + (size_t)RM * j + SS * s] *= a;
+    }
+}
 __global__ void k_scal(size_t n, double *x, double a)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= a;
