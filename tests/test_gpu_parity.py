@@ -518,3 +518,23 @@ def test_chf_driver_against_oracle():
     assert abs(vals[0].imag) <= 1e-12 * scale                  # omega = 0: real weights
     for k in range(32):
         assert abs(vals[k] - oref.zquad(W[k])) <= 1e-9 * scale
+
+
+def test_fortran_chf_dropin_matches_python_driver():
+    """N2 behind the Fortran boundary: the drop-in `ztt` type, `tt_z = tt` and `ztt_quad` (ttcross_amd/fortran) in a
+    driver with the pipeline of test_crs_chf.f90, against the Python driver on the same arguments.  Both run the same
+    engine; the complex weights come from two different libm's, hence 1e-12 instead of bit equality."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ttcross_amd", "fortran", "build", "test_crs_chf")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran layer not built (needs amdflang)")
+    p = subprocess.run([exe, "5", "17", "8", "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = {int(ln.split()[2]): complex(float(ln.split()[3]), float(ln.split()[4])) for ln in p.stdout.splitlines() if ln.startswith("computed value:")}
+    assert sorted(got) == list(range(32))
+    _, vals, _ = D.run_chf(["5", "17", "8", "2"], verbose=False)
+    scale = abs(vals[0])
+    for k in range(32):
+        assert abs(got[k] - vals[k]) <= 1e-12 * scale, (k, got[k], vals[k])

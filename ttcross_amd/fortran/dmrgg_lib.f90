@@ -91,6 +91,30 @@ contains
   val=v
  end function
 
+ double complex function ztt_quad(arg,quad,mybonds) result(val)
+  ! lib/dmrgg.f90:1418: quadrature of the (real) device train behind arg with the COMPLEX rank-1 weights in quad
+  type(ztt),intent(in),target :: arg
+  type(ztt),intent(in),optional :: quad
+  integer,intent(in),optional,target :: mybonds(0:)
+  real(c_double),allocatable :: w(:)
+  real(c_double) :: o(2)
+  integer :: k,j,off
+  if(.not.c_associated(arg%ttx))then;write(*,*)'ztt_quad: the train was not made from a dtt that is resident on the device';stop;endif
+  allocate(w(2*sum(arg%n(1:arg%m)))); off=0
+  do k=1,arg%m
+   do j=1,arg%n(k)
+    if(present(quad))then
+     w(off+2*j-1)=dble(quad%u(k)%p(1,j,1)); w(off+2*j)=dimag(quad%u(k)%p(1,j,1))
+    else
+     w(off+2*j-1)=1.d0; w(off+2*j)=0.d0
+    end if
+   end do
+   off=off+2*arg%n(k)
+  end do
+  call ttx_check(ttx_zquad(arg%ttx,1_c_int32_t,w,o),'ztt_quad')
+  val=dcmplx(o(1),o(2))
+ end function
+
  subroutine dtt_accchk(nlot,arg,einf,efro,ainf,afro,fun,par,pivot)
   ! lib/dmrgg.f90:1081: random-sample error of the TT held by the engine against the integrand it was built from
   integer,intent(in) :: nlot

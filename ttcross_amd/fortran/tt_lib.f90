@@ -6,6 +6,9 @@ module ptype_lib
  type,public :: pointd3
   double precision,dimension(:,:,:),pointer,contiguous :: p=>null()
  end type
+ type,public :: pointz3
+  double complex,dimension(:,:,:),pointer,contiguous :: p=>null()
+ end type
 end module
 
 module tt_lib
@@ -24,8 +27,22 @@ module tt_lib
   type(pointd3) :: u(tt_size)
   type(c_ptr) :: ttx=c_null_ptr      ! engine handle after dtt_dmrgg (not in the reference)
  end type
- interface alloc;   module procedure dtt_alloc;   end interface
- interface dealloc; module procedure dtt_dealloc; end interface
+ ! complex train (lib/tt.f90:38-52): host cores as in the reference; a ztt made from a dtt (tt_z = tt) also BORROWS
+ ! the device train of that dtt -- ztt_quad works on it -- and never releases it
+ type,public :: ztt
+  integer :: l=1
+  integer :: m=0
+  integer :: n(tt_size)=0
+  integer :: q(tt_size)=0
+  integer :: s(tt_size)=0
+  integer :: t=0
+  integer :: r(0:tt_size)=0
+  type(pointz3) :: u(tt_size)
+  type(c_ptr) :: ttx=c_null_ptr
+ end type
+ interface alloc;   module procedure dtt_alloc,ztt_alloc;     end interface
+ interface dealloc; module procedure dtt_dealloc,ztt_dealloc; end interface
+ interface assignment (=); module procedure ztt_dtt_assign; end interface
  interface ones;    module procedure dtt_ones;    end interface
  interface erank;   module procedure dtt_rank;    end interface
  ! utilities that run on the tensor train resident on the device after dtt_dmrgg (lib/tt.f90:54-124 generics)
@@ -35,6 +52,43 @@ module tt_lib
  interface dot_product; module procedure dtt_dot;  end interface
  interface tijk;        module procedure dtt_ijk;  end interface
 contains
+ subroutine ztt_alloc(arg)
+  type(ztt),intent(inout) :: arg
+  integer :: k,ierr
+  if(arg%m < arg%l) return
+  do k = arg%l, arg%m
+   if(associated(arg%u(k)%p)) deallocate(arg%u(k)%p)
+   allocate(arg%u(k)%p(arg%r(k-1), arg%n(k), arg%r(k)), stat=ierr)
+   if(ierr /= 0) then
+    write(*,*) 'TT allocate fail: no memory'; stop
+   end if
+  end do
+ end subroutine
+ subroutine ztt_dealloc(arg)
+  type(ztt),intent(inout) :: arg
+  integer :: k
+  do k = 1, tt_size
+   if(associated(arg%u(k)%p)) then
+    deallocate(arg%u(k)%p); nullify(arg%u(k)%p)
+   end if
+  end do
+  arg%ttx = c_null_ptr               ! borrowed, see the type
+ end subroutine
+ subroutine ztt_dtt_assign(z,d)
+  ! lib/tt.f90:1033-1045: complex copy of a real train (plus the borrowed device handle)
+  type(ztt),intent(inout) :: z
+  type(dtt),intent(in) :: d
+  integer :: k
+  if(d%l > d%m) then
+   write(*,*) 'ztt_dtt_assign: l,m: ',d%l,d%m; return
+  end if
+  z%l = d%l; z%m = d%m; z%n = d%n; z%r = d%r
+  call ztt_alloc(z)
+  do k = d%l, d%m
+   z%u(k)%p = dcmplx(d%u(k)%p, 0.d0)
+  end do
+  z%ttx = d%ttx
+ end subroutine
  subroutine dtt_alloc(arg)
   ! (re)allocate every core k = l..m with the shape (r(k-1), n(k), r(k))
   type(dtt),intent(inout) :: arg

@@ -73,6 +73,9 @@ module ttx_c
    import; type(c_ptr),value :: h; integer(c_int32_t),value :: nlot; real(c_double),intent(out) :: einf,efro,ainf,afro
    integer(c_int32_t),intent(out) :: pivot(*); integer(c_int) :: rc
   end function
+  function ttx_zquad(h,nf,w,out) bind(C,name='ttx_zquad') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int32_t),value :: nf; real(c_double) :: w(*),out(*); integer(c_int) :: rc
+  end function
   function ttx_from_tt(h,d,n,r,cores,device) bind(C,name='ttx_from_tt') result(rc)
    import; type(c_ptr) :: h; integer(c_int32_t),value :: d,device; integer(c_int32_t) :: n(*),r(*); real(c_double) :: cores(*); integer(c_int) :: rc
   end function
