@@ -29,6 +29,8 @@ WORKLOADS = {
     "c64": (("ising", "c", 64, 51, 32, 2), "Ising C_64 n=51 r=32 piv=2 (d=63)"),
     "c16": (("ising", "c", 16, 51, 32, 2), "Ising C_16 n=51 r=32 piv=2 (d=15)"),
     "d32": (("ising", "d", 32, 51, 24, 2), "Ising D_32 n=51 r=24 piv=2 (d=31)"),
+    # BASELINE config 5 at full size: about 12 s per step on one MI355X (use --steps 1 --warmup 0 --no-cpu-baseline)
+    "d256": (("ising", "d", 256, 101, 64, 5), "Ising D_256 n=101 r=64 piv=5 (d=255)"),
 }
 FP64_VECTOR_PEAK_TFLOPS = 78.0      # MI355X fp64 vector (non-matrix) peak, SURVEY 8(d)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
