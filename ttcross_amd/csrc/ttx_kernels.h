@@ -1201,8 +1201,13 @@ __global__ __launch_bounds__(256) void k_quad_build(DevProb P, int mode, const d
         int i = x % r0, k = x / r0;
         const double *a = A + i + P.SS * k;
         double y = 0.0;
-        if (w) for (int j = 0; j < n; j++) y = y + w[j] * a[(size_t)RM * j];     // dgemv 'n', :988 / :1327
-        else   for (int j = 0; j < n; j++) y = y + a[(size_t)RM * j];            // :1331
+        if (w) {
+#pragma unroll 8
+            for (int j = 0; j < n; j++) y = y + w[j] * a[(size_t)RM * j];        // dgemv 'n', :988 / :1327
+        } else {
+#pragma unroll 8
+            for (int j = 0; j < n; j++) y = y + a[(size_t)RM * j];               // :1331
+        }
         T[i + RM * k] = y;
     }
     __syncthreads();
@@ -1253,6 +1258,7 @@ __global__ __launch_bounds__(256) void k_quad_chain(DevProb P)
         for (int x = tid; x < mym * r1; x += blockDim.x) {
             int i = x % mym, j = x / mym;
             double c = 0.0;
+#pragma unroll 8
             for (int l = 0; l < r0; l++) c = c + Tc[l + RM * j] * prev[i + RM * l];
             next[i + RM * j] = c;
         }
