@@ -790,8 +790,14 @@ static int run_impl(ttx_engine *h)
             if ((rc = xfer_neighbours(h))) return rc;
             hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
         }
-        hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), 0, st, P);
+        const size_t lds_f = sizeof(double) * ((size_t)h->RM * h->RM + 256 * (size_t)h->RM);
+        const int fl = lds_f <= 150 * 1024 ? 1 : 0;
+        if (fl) {
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fin_luar), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fin_lual), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+        }
+        hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), fl ? lds_f : 0, st, P, fl);
+        hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), fl ? lds_f : 0, st, P, fl);
     }
     if ((rc = readback(h))) return rc;
     HIPCHECK(hipGetLastError());
