@@ -711,7 +711,7 @@ static int run_impl(ttx_engine *h)
             }
             hipLaunchKernelGGL(k_exch_max_apply, dim3(G), dim3(256), 0, st, P, h->W > 1 ? 1 : 0, nproc > 1 ? 1 : 0);
             if (nproc > 1)
-                hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + sizeof(short) * (d + 8) + sizeof(double) * (64 * 64 + 4), st, P);
+                hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + 16 + sizeof(short) * 2 * (((d + 7) & ~7) + 8) + sizeof(double) * (64 * 64 + 4), st, P);
         }
         if (pipe) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
         if (P.has_quad) {

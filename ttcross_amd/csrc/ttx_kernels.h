@@ -1540,8 +1540,11 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
     const int first = gs.first, last = gs.last;
     const int *r = P.r + (size_t)g * (m + 2), *rr = P.rr + (size_t)g * (m + 2), *upd = P.upd + (size_t)g * (m + 2);
     double *par = dyn;
-    short *row = (short *)(dyn + P.npar);      // one full multi-index (m shorts) for the corner evaluation
-    double *lu = dyn + P.npar + ((m + 8 + 3) >> 2) + 1;   // packed LU of the boundary bond (ranks <= 64)
+    // corner evaluation: the multi-index as two 16-byte aligned, padded rows (dims 1..p-1 | dims p+1..m) around dim p,
+    // the layout the fast chunked evaluators read
+    const int VSr = ((m + 7) & ~7) + 8;
+    short *rowA = (short *)(((size_t)(dyn + P.npar) + 15) & ~(size_t)15), *rowB = rowA + VSr;
+    double *lu = (double *)(rowB + VSr);                  // packed LU of the boundary bond (ranks <= 64)
     if ((int)blockIdx.x < P.NM) {
         const int k = blockIdx.x, p = last, br = last + 1;
         if (!P.inR[g] || !upd[br] || k >= P.n[br]) return;
@@ -1554,12 +1557,12 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
             for (int x = tid; x < P.npar; x += TTX_BLK) par[x] = P.par[x];
             const int *vp = vip_ptr(P, g, p, first) + 4 * (rp - 1);
             const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, br, first);
-            for (int s = 1 + tid; s <= m; s += TTX_BLK)
-                row[s - 1] = (s < p) ? Lt[(size_t)(s - 1) * P.RM + (vp[0] - 1)] : (s == p) ? (short)vp[1] : (s == p + 1) ? (short)(k + 1) : Rt[(size_t)(s - p - 2) * P.RM + snew];
+            auto dimv = [&](int s) -> short { return (s < p) ? Lt[(size_t)(s - 1) * P.RM + (vp[0] - 1)] : (s == p) ? (short)vp[1] : (s == p + 1) ? (short)(k + 1) : Rt[(size_t)(s - p - 2) * P.RM + snew]; };
+            for (int x = tid; x < VSr; x += TTX_BLK) { rowA[x] = (x < p - 1) ? dimv(x + 1) : (short)1; rowB[x] = (x < m - p) ? dimv(p + 1 + x) : (short)1; }
             __syncthreads();
             if (tid == rrp) {
-                Src3 sx{row, p - 1, (int)row[p - 1], row + p};
-                a = eval_src3<FUN, false>(P, par, sx);
+                Src3 sx{rowA, p - 1, (int)vp[1], rowB};
+                a = eval_src3<FUN, true>(P, par, sx);
                 atomic_max_pos(&gs.amax, fabs(a));
                 if (k == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n2);   // :936
             }
@@ -1599,12 +1602,12 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
             for (int x = tid; x < P.npar; x += TTX_BLK) par[x] = P.par[x];
             const int *vp = vip_ptr(P, g, p, first) + 4 * (rp - 1);
             const short *Lt = L_ptr(P, g, bl, first), *Rt = R_ptr(P, g, p + 1, first);
-            for (int s = 1 + tid; s <= m; s += TTX_BLK)
-                row[s - 1] = (s < p) ? Lt[(size_t)(s - 1) * P.RM + inew] : (s == p) ? (short)(j + 1) : (s == p + 1) ? (short)vp[2] : Rt[(size_t)(s - p - 2) * P.RM + (vp[3] - 1)];
+            auto dimv = [&](int s) -> short { return (s < p) ? Lt[(size_t)(s - 1) * P.RM + inew] : (s == p) ? (short)(j + 1) : (s == p + 1) ? (short)vp[2] : Rt[(size_t)(s - p - 2) * P.RM + (vp[3] - 1)]; };
+            for (int x = tid; x < VSr; x += TTX_BLK) { rowA[x] = (x < p - 1) ? dimv(x + 1) : (short)1; rowB[x] = (x < m - p) ? dimv(p + 1 + x) : (short)1; }
             __syncthreads();
             if (tid == rrp) {
-                Src3 sx{row, p - 1, (int)row[p - 1], row + p};
-                y = eval_src3<FUN, false>(P, par, sx);
+                Src3 sx{rowA, p - 1, j + 1, rowB};
+                y = eval_src3<FUN, true>(P, par, sx);
                 atomic_max_pos(&gs.amax, fabs(y));
                 if (j == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n1);
             }
