@@ -248,6 +248,15 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     A_(dev_alloc(h, &P.acol, G * RM * NM)); A_(dev_alloc(h, &P.arow, G * RM * NM));
     A_(dev_alloc(h, &P.Tq, G * NC * RM * RM));
     A_(dev_alloc(h, &P.ind0, d + 2)); A_(dev_alloc(h, &P.gs, G));
+    {   // the bond range of every local group is fixed for the life of the engine (k_reset leaves it alone)
+        GroupState *g0s = (GroupState *)calloc(1, sizeof(GroupState));
+        for (size_t g = 0; g < G; g++) {
+            g0s->first = h->own[h->g0 + g]; g0s->last = h->own[h->g0 + g + 1] - 1; g0s->gglobal = h->g0 + (int)g;
+            hipError_t e = hipMemcpy(P.gs + g, g0s, offsetof(GroupState, S), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { free(g0s); ttx_destroy(h); return fail(TTX_EHIP, "ttx_create: %s", hipGetErrorString(e)); }
+        }
+        free(g0s);
+    }
     P.nfb = (int)((RM * NM + TTX_BLK - 1) / TTX_BLK);
     if (cfg->pivoting < 0) A_(dev_alloc(h, &P.pfull, G * NM * RM * (size_t)P.nfb));
     // exchange buffers
@@ -610,20 +619,7 @@ static int run_impl(ttx_engine *h)
     if (h->cluster) *h->h_abort = 0;
     if (h->cluster) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_cluster));
     // ---- reset state (lib/dmrgg.f90:96-100, 141-148, 279-288) ----
-    {
-        std::vector<GroupState> gs(G);
-        memset(gs.data(), 0, sizeof(GroupState) * G);
-        for (int g = 0; g < G; g++) { gs[g].first = h->own[h->g0 + g]; gs[g].last = h->own[h->g0 + g + 1] - 1; gs[g].gglobal = h->g0 + g; gs[g].pivotmax = -1.0; gs[g].pivotmin = -1.0; }
-        HIPCHECK(hipMemcpyAsync(P.gs, gs.data(), sizeof(GroupState) * G, hipMemcpyHostToDevice, st));
-        std::vector<int32_t> ones((size_t)G * (d + 2), 1), m1((size_t)G * (d + 2) * 4, -1);
-        HIPCHECK(hipMemcpyAsync(P.r, ones.data(), sizeof(int32_t) * ones.size(), hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(P.rr, ones.data(), sizeof(int32_t) * ones.size(), hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(P.tape, m1.data(), sizeof(int32_t) * m1.size(), hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemsetAsync(P.upd, 0, sizeof(int32_t) * (size_t)G * (d + 2), st));
-        HIPCHECK(hipMemsetAsync(P.sumsend, 0, sizeof(double) * h->SB, st));
-        HIPCHECK(hipMemsetAsync(P.qsend, 0, sizeof(double) * h->QB, st));
-        HIPCHECK(hipStreamSynchronize(st));   // host vectors go out of scope
-    }
+    hipLaunchKernelGGL(k_reset, dim3(64), dim3(256), 0, st, P, h->SB, h->QB);
     // ---- initial cross (:151-301) ----
     const int smin = 8, snum = std::max(smin, nproc);
     int nn = h->n1[1];
@@ -635,7 +631,24 @@ static int run_impl(ttx_engine *h)
         hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), 0, st, P);
         hipLaunchKernelGGL(k_init_final, dim3(G), dim3(256), 0, st, P);
     }
-    if ((rc = readback(h))) return rc;
+    // Single-process whole-sweep path: the first sweep kernel is enqueued right behind the initial cross, and the host
+    // waits only for the copy of the initial summary (an event), not for the stream.
+    const bool pipe0 = (h->cluster || h->fused) && h->W == 1 && !h->profile;
+    bool head1 = false;
+    if (pipe0) {
+        hipLaunchKernelGGL(k_collect, dim3(1), dim3(256), 0, st, P);
+        h->h_sum = h->h_sum_base;
+        HIPCHECK(hipMemcpyAsync(h->h_sum, P.sumrecv, sizeof(double) * h->SB, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipEventRecord(h->ev_sum[0], st));
+        if (1 < h->cfg.maxrank) {
+            if (h->cluster) hipLaunchKernelGGL(k_sweep_cluster, dim3(8 * h->cluster * ((G + 7) / 8)), dim3(CB), h->lds_cluster, st, P, 1, h->nbmax, h->cluster,
+                                               h->cluster_ldsinv, 1, h->cluster_zkeep);
+            else hipLaunchKernelGGL(k_sweep_fused, dim3(G), dim3(FB), h->lds_fused, st, P, 1, h->nbmax);
+            h->k_launches[TTX_K_HALFSTEP] += 1;
+            head1 = true;
+        }
+        HIPCHECK(hipEventSynchronize(h->ev_sum[0]));
+    } else if ((rc = readback(h))) return rc;
     HIPCHECK(hipGetLastError());
     double val = 1.0, val_prev = 1.0;
     for (int g = 0; g < nproc; g++) val = (g == 0) ? h->h_sum[SUM_HDR + g] : val * h->h_sum[SUM_HDR + g];   // :259-267 PROD
@@ -660,16 +673,13 @@ static int run_impl(ttx_engine *h)
     // following sweep: it reads a snapshot of the ranks and only slabs that already exist (appends are in place).
     const bool pipe = (h->cluster || h->fused) && h->W == 1 && !h->profile;
     const bool forkq = pipe && P.has_quad;
-    HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 4, st));
-    if (h->cluster) {
-        HIPCHECK(hipMemsetAsync(P.cl_ctr, 0, sizeof(unsigned) * G, st));
-        HIPCHECK(hipMemsetAsync(P.cl_part, 0, sizeof(ClPart) * 2 * G * TTX_CLMAX, st));
-    }
     DevProb Pq = P;
     if (pipe) Pq.r = P.rq;
 
-    auto enqueue_sweep = [&](int it_) -> int {
+    // part 1: the sweep over the own bonds; part 2: exchange, end-of-sweep work, quadrature; 3: both
+    auto enqueue_sweep = [&](int it_, int part) -> int {
         const int dir = 2 - it_ % 2, slot = it_ & 1;
+        if (part & 1) {
         if (h->cluster) {
             KScope ks(h, TTX_K_HALFSTEP, 1);
             hipLaunchKernelGGL(k_sweep_cluster, dim3(8 * h->cluster * ((G + 7) / 8)), dim3(CB), h->lds_cluster, st, P, dir, h->nbmax, h->cluster,
@@ -700,6 +710,8 @@ static int run_impl(ttx_engine *h)
             }
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }
+        }
+        if (!(part & 2)) return TTX_OK;
         if (forkq) HIPCHECK(hipStreamWaitEvent(st, h->ev_val[slot ^ 1], 0));   // the previous quadrature is done with the boundaries
         {   // per-sweep exchange between bond groups (:763-961)
             KScope ks(h, TTX_K_EXCHANGE, (h->W > 1 ? 4 : 2) + (nproc > 1 ? 1 : 0));
@@ -767,14 +779,17 @@ static int run_impl(ttx_engine *h)
     if (!pipe) {
         while (!ready) {
             it++;
-            if ((rc = enqueue_sweep(it))) return rc;
+            if ((rc = enqueue_sweep(it, 3))) return rc;
             if ((rc = process_sweep(it))) return rc;
         }
     } else if (!ready) {
+        // only the sweep kernel of it+1 is enqueued speculatively (it keeps the GPU busy while the host reads the summary of
+        // sweep it); once the rule has fired that one launch finds the stop flag and exits, and its tail is never enqueued
         if (forkq) { HIPCHECK(hipEventRecord(h->ev_val[0], h->qstream)); HIPCHECK(hipEventRecord(h->ev_val[1], h->qstream)); }
-        if ((rc = enqueue_sweep(1))) return rc;
+        if (!head1 && (rc = enqueue_sweep(1, 1))) return rc;
         for (it = 1; !ready; it++) {
-            if (it + 1 < h->cfg.maxrank && (rc = enqueue_sweep(it + 1))) return rc;    // a no-op on the device once the rule has fired
+            if ((rc = enqueue_sweep(it, 2))) return rc;
+            if (it + 1 < h->cfg.maxrank && (rc = enqueue_sweep(it + 1, 1))) return rc;
             if ((rc = process_sweep(it))) return rc;
         }
         it--;

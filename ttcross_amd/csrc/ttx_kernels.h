@@ -661,6 +661,32 @@ __global__ __launch_bounds__(256) void k_init_final(DevProb P)
     if (tid == 0) { gs.pivotmax_prev = gs.amax; gs.pivotmax = -1.0; gs.pivotmin = -1.0; gs.initval = val; }
 }
 
+// start of a run (lib/dmrgg.f90:96-100, 141-148, 279-288): every per-run quantity back to its initial value in ONE launch
+// (the bond ranges first/last/gglobal of the groups never change and are set when the engine is created)
+__global__ __launch_bounds__(256) void k_reset(DevProb P, size_t SB, size_t QB)
+{
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    const size_t nr = (size_t)P.G * (P.d + 2);
+    for (size_t x = t0; x < nr; x += nt) { P.r[x] = 1; P.rr[x] = 1; P.upd[x] = 0; }
+    for (size_t x = t0; x < 4 * nr; x += nt) P.tape[x] = -1;
+    for (size_t x = t0; x < SB; x += nt) P.sumsend[x] = 0.0;
+    for (size_t x = t0; x < QB; x += nt) P.qsend[x] = 0.0;
+    if (t0 < 4) P.ctl[t0] = 0;
+    if (P.cl_ctr) {
+        for (size_t x = t0; x < (size_t)P.G; x += nt) P.cl_ctr[x] = 0u;
+        ClPart z; z.ab = 0.0; z.bb = 0.0; z.mx = 0.0; z.ix = 0; z.pad = 0;
+        for (size_t x = t0; x < (size_t)2 * P.G * TTX_CLMAX; x += nt) P.cl_part[x] = z;
+    }
+    for (size_t g = t0; g < (size_t)P.G; g += nt) {
+        GroupState &gs = P.gs[g];
+        gs.amax = 0.0; gs.pivotmax = -1.0; gs.pivotmin = -1.0; gs.pivotmax_prev = 0.0;
+        gs.neval = 0; gs.rngpos = 0; gs.val = 0.0; gs.initval = 0.0; gs.bytes_half = 0.0; gs.n_resid = 0;
+#ifdef TTX_STAMPS
+        for (int a = 0; a < 2; a++) { gs.nstamp[a] = 0; for (int b = 0; b < 16; b++) gs.stamp[a][b] = 0; }
+#endif
+    }
+}
+
 // snapshot of the bond this group works on at step pp of the sweep (:325-335); thread 0 only
 __device__ inline void bond_state(const DevProb &P, int g, int dir, int pp, StepState &st)
 {
