@@ -111,7 +111,7 @@ struct ttx_engine {
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
     hipStream_t qstream = nullptr;      // forked per-sweep quadrature (single-process runs)
-    hipEvent_t ev_fork = nullptr, ev_sum[2] = {nullptr, nullptr}, ev_val[2] = {nullptr, nullptr};
+    hipEvent_t ev_sum[2] = {nullptr, nullptr}, ev_val[2] = {nullptr, nullptr};
     double *h_sum_base = nullptr;       // pinned [2][SB]: summaries of the two sweeps in flight
     double *h_val = nullptr;            // pinned [2]: per-sweep quadrature values
     int cluster_zkeep = 0;              // cluster kernel keeps the sorted pivot lists of all own bonds in LDS
@@ -293,7 +293,6 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     memset(h->h_sum_base, 0, sizeof(double) * 2 * h->SB);
     HIPCHECK(hipHostMalloc((void **)&h->h_val, sizeof(double) * 2));
     HIPCHECK(hipStreamCreateWithFlags(&h->qstream, hipStreamNonBlocking));
-    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int x = 0; x < 2; x++) { HIPCHECK(hipEventCreateWithFlags(&h->ev_sum[x], hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_val[x], hipEventDisableTiming)); }
     HIPCHECK(hipHostMalloc((void **)&h->h_msg, 4 * P.MSZ));
     HIPCHECK(hipHostMalloc((void **)&h->h_tmp, sizeof(double) * std::max(h->QB, h->SB)));
@@ -389,7 +388,6 @@ extern "C" void ttx_destroy(ttx_engine *h)
     if (h->h_sum_base) (void)hipHostFree(h->h_sum_base);
     if (h->h_val) (void)hipHostFree(h->h_val);
     if (h->qstream) (void)hipStreamDestroy(h->qstream);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int x = 0; x < 2; x++) { if (h->ev_sum[x]) (void)hipEventDestroy(h->ev_sum[x]); if (h->ev_val[x]) (void)hipEventDestroy(h->ev_val[x]); }
     if (h->h_msg) (void)hipHostFree(h->h_msg);
     if (h->h_tmp) (void)hipHostFree(h->h_tmp);
@@ -726,9 +724,10 @@ static int run_impl(ttx_engine *h)
                 hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + 16 + sizeof(short) * 2 * (((d + 7) & ~7) + 8) + sizeof(double) * (64 * 64 + 4), st, P);
         }
         if (pipe) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
+        if (pipe) HIPCHECK(hipEventRecord(h->ev_sum[slot], st));     // k_sweep_end wrote the summary into the pinned slot
         if (P.has_quad) {
             hipStream_t sq = forkq ? h->qstream : st;
-            if (forkq) { HIPCHECK(hipEventRecord(h->ev_fork, st)); HIPCHECK(hipStreamWaitEvent(sq, h->ev_fork, 0)); }
+            if (forkq) HIPCHECK(hipStreamWaitEvent(sq, h->ev_sum[slot], 0));    // fork point = end of the sweep's main-stream work
             KScope ks(h, TTX_K_QUAD, nproc > 1 ? 3 : 2);
             const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
             hipLaunchKernelGGL(k_quad_build, dim3(h->NC, G), dim3(256), lds_q, sq, pipe ? Pq : P, 0, P.quadw);
@@ -742,7 +741,6 @@ static int run_impl(ttx_engine *h)
                 HIPCHECK(hipEventRecord(h->ev_val[slot], sq));
             }
         }
-        if (pipe) HIPCHECK(hipEventRecord(h->ev_sum[slot], st));     // k_sweep_end wrote the summary into the pinned slot
         return TTX_OK;
     };
     // host side of a finished sweep: record, tapes, log line, stopping rule (identical to k_sweep_end)
