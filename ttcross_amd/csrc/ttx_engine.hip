@@ -598,6 +598,15 @@ static int launch_quad(ttx_engine *h, int mode, const double *w)
     return TTX_OK;
 }
 
+// raise a kernel's dynamic-LDS ceiling to `need` bytes if no earlier launch asked for as much (`cur`: the caller's record)
+static int ensure_lds(const void *fn, size_t need, size_t &cur)
+{
+    if (need <= cur) return TTX_OK;
+    HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    cur = need;
+    return TTX_OK;
+}
+
 template <int FUN>
 static int run_impl(ttx_engine *h)
 {
@@ -611,11 +620,14 @@ static int run_impl(ttx_engine *h)
     int rc;
 
     // kernels that may stage more than the default 64 KB of dynamic LDS (160 KB per CU on gfx950)
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_halfstep<FUN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_half));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lottery<FUN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_lot));
-    if (h->fused) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fused));
+    {   // the dynamic-LDS ceiling is a property of the FUNCTION: raise it when an engine needs more than any before it
+        static size_t a_half = 0, a_lot = 0, a_fused = 0, a_cluster = 0;        // per instantiation (FUN) of this template
+        if ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep<FUN>), h->lds_half, a_half))) return rc;
+        if ((rc = ensure_lds(reinterpret_cast<const void *>(k_lottery<FUN>), h->lds_lot, a_lot))) return rc;
+        if (h->fused && (rc = ensure_lds(reinterpret_cast<const void *>(k_sweep_fused), h->lds_fused, a_fused))) return rc;
+        if (h->cluster && (rc = ensure_lds(reinterpret_cast<const void *>(k_sweep_cluster), h->lds_cluster, a_cluster))) return rc;
+    }
     if (h->cluster) *h->h_abort = 0;
-    if (h->cluster) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_cluster));
     // ---- reset state (lib/dmrgg.f90:96-100, 141-148, 279-288) ----
     hipLaunchKernelGGL(k_reset, dim3(64), dim3(256), 0, st, P, h->SB, h->QB);
     // ---- initial cross (:151-301) ----
@@ -743,12 +755,43 @@ static int run_impl(ttx_engine *h)
         }
         return TTX_OK;
     };
+    // ---- finalise (:1029): dtt_lua shifts the rightmost inv of every group to its neighbour first.  Enqueued once; in the
+    //      pipelined loop as soon as the stopping rule has fired on the host (after_val >= 0: the slot whose forked quadrature
+    //      still reads the cores the finalisation overwrites -- a stream-side wait, the host does not idle) ----
+    bool fin_enqueued = false;
+    auto enqueue_final = [&](int after_val) -> int {
+        if (fin_enqueued) return TTX_OK;
+        fin_enqueued = true;
+        if (after_val >= 0) HIPCHECK(hipStreamWaitEvent(st, h->ev_val[after_val], 0));
+        HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 4, st));
+        KScope ks(h, TTX_K_OTHER, 2);
+        if (nproc > 1) {
+            hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
+            if (int rc_ = xfer_neighbours(h)) return rc_;
+            hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
+        }
+        const size_t lds_f = sizeof(double) * ((size_t)h->RM * h->RM + 256 * (size_t)h->RM);
+        const int fl = lds_f <= 150 * 1024 ? 1 : 0;
+        if (fl) {
+            static size_t a_luar = 0, a_lual = 0;
+            if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_fin_luar), lds_f, a_luar)) return rc_;
+            if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_fin_lual), lds_f, a_lual)) return rc_;
+        }
+        hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), fl ? lds_f : 0, st, P, fl);
+        hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), fl ? lds_f : 0, st, P, fl);
+        return TTX_OK;
+    };
     // host side of a finished sweep: record, tapes, log line, stopping rule (identical to k_sweep_end)
     auto process_sweep = [&](int it_) -> int {
         const int dir = 2 - it_ % 2, slot = it_ & 1;
         if (pipe) {
             HIPCHECK(hipEventSynchronize(h->ev_sum[slot]));
             h->h_sum = h->h_sum_base + (size_t)slot * h->SB;
+            {   // the rule needs only the summary: if it fires, the finalisation goes out before the host waits for the value
+                bool rdy = (it_ + 1 >= h->cfg.maxrank);
+                if (h->cfg.accuracy >= 0.0) rdy = rdy || (((h->h_sum[SUM_PMAX] <= h->cfg.accuracy * h->h_sum[SUM_AMAX]) ? strike + 1 : 0) >= 3);
+                if (rdy) { if (int rc_ = enqueue_final(P.has_quad ? slot : -1)) return rc_; }
+            }
             if (P.has_quad) { HIPCHECK(hipEventSynchronize(h->ev_val[slot])); val = h->h_val[slot]; }
         } else {
             if (int rc_ = readback(h)) return rc_;
@@ -791,27 +834,8 @@ static int run_impl(ttx_engine *h)
             if ((rc = process_sweep(it))) return rc;
         }
         it--;
-        HIPCHECK(hipStreamSynchronize(st));
-        if (forkq) HIPCHECK(hipStreamSynchronize(h->qstream));
-        HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 4, st));
     }
-    // ---- finalise (:1029): dtt_lua shifts the rightmost inv of every group to its neighbour first ----
-    {
-        KScope ks(h, TTX_K_OTHER, 2);
-        if (nproc > 1) {
-            hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
-            if ((rc = xfer_neighbours(h))) return rc;
-            hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
-        }
-        const size_t lds_f = sizeof(double) * ((size_t)h->RM * h->RM + 256 * (size_t)h->RM);
-        const int fl = lds_f <= 150 * 1024 ? 1 : 0;
-        if (fl) {
-            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fin_luar), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fin_lual), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-        }
-        hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), fl ? lds_f : 0, st, P, fl);
-        hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), fl ? lds_f : 0, st, P, fl);
-    }
+    if ((rc = enqueue_final(-1))) return rc;
     if ((rc = readback(h))) return rc;
     HIPCHECK(hipGetLastError());
 #ifdef TTX_STAMPS
