@@ -636,7 +636,11 @@ static int run_impl(ttx_engine *h)
     for (int k = 2; k <= d; k++) nn = std::min(nn, h->n1[k]);
     {
         KScope ks(h, TTX_K_OTHER, 4);
-        hipLaunchKernelGGL(k_init_samples<FUN>, dim3(G), dim3(256), h->lds_par, st, P, snum, nn, 0, 0);
+        const size_t lds_s = h->lds_par + 16 + sizeof(short) * 256 * (size_t)(((d + 7) & ~7) + 8);
+        const int srows = lds_s <= 150 * 1024 ? 1 : 0;
+        static size_t a_samp = 0;
+        if (srows && (rc = ensure_lds(reinterpret_cast<const void *>(k_init_samples<FUN>), lds_s, a_samp))) return rc;
+        hipLaunchKernelGGL(k_init_samples<FUN>, dim3(G), dim3(256), srows ? lds_s : h->lds_par, st, P, snum, nn, srows, 0);
         hipLaunchKernelGGL(k_init_fibers<FUN>, dim3(h->NC, G), dim3(256), h->lds_par, st, P);
         hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), 0, st, P);
         hipLaunchKernelGGL(k_init_final, dim3(G), dim3(256), 0, st, P);

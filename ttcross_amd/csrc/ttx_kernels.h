@@ -536,7 +536,7 @@ struct FixIdx { const int *ind; int self, selfval; __device__ __forceinline__ in
 // every group evaluates all nn*snum shifted-diagonal samples (a few hundred) so that the MAXLOC of :196
 // needs no exchange; each group is charged only its own share of evaluations (:160,181)
 template <int FUN>
-__global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int nn, int shift_lo, int shift_hi)
+__global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int nn, int ldsrows, int shift_hi)
 {
     extern __shared__ __align__(16) double dyn[];
     double *par = dyn;
@@ -546,9 +546,28 @@ __global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int n
     for (int x = tid; x < P.npar; x += blockDim.x) par[x] = P.par[x];
     __syncthreads();
     double ba = -1.0, bv = 0.0; int bi = INT_MAX;
+    // each thread writes the multi-index of its sample once into an aligned, padded LDS row (dims 1..m-1 | dim m) and
+    // evaluates through the chunked evaluators instead of recomputing the shifted-diagonal index in every pass
+    const int m = P.d, VSr = ((m + 7) & ~7) + 8;
+    short *rows = (short *)(((size_t)(dyn + P.npar) + 15) & ~(size_t)15);
+    short *row = rows + (size_t)tid * VSr;
+    if (!ldsrows)                                             // rows do not fit the LDS: generic accessor
+        for (int il = tid; il < nn * snum; il += blockDim.x) {
+            DiagIdx ix{P.n, il % nn + 1, il / nn};
+            double f = eval_fun<FUN>(P, par, ix);
+            double a = fabs(f);
+            if (a > ba || (a == ba && il < bi)) { ba = a; bv = f; bi = il; }
+        }
+    else
     for (int il = tid; il < nn * snum; il += blockDim.x) {
-        DiagIdx ix{P.n, il % nn + 1, il / nn};
-        double f = eval_fun<FUN>(P, par, ix);
+        const int k = il % nn + 1, sft = il / nn;
+        for (int p = 1; p <= m; p++) row[p - 1] = (short)((k - 1 + sft * (p - 1)) % P.n[p] + 1);
+        for (int x = m; x < VSr; x++) row[x] = 1;
+        row[m - 1 + 0] = row[m - 1];                          // (dim m stays readable as `self`)
+        const int self = row[m - 1];
+        row[m - 1] = 1;                                       // pad of the dims 1..m-1 part
+        Src3 sx{row, m - 1, self, row + m};                   // empty right part: nb = 0, never read
+        double f = eval_src3<FUN, true>(P, par, sx);
         double a = fabs(f);
         if (a > ba || (a == ba && il < bi)) { ba = a; bv = f; bi = il; }
     }
