@@ -447,7 +447,7 @@ static void fmt_e(char *out, int w, int dgt, double v)
         snprintf(body, sizeof body, ".%sE+00", z);
     }
     int len = (int)strlen(body);
-    if (len + 1 <= w) { snprintf(tmp, sizeof tmp, "0%s", body); snprintf(out, 64, "%*s", w, tmp); }
+    if (len + 1 <= w) { tmp[0] = '0'; memcpy(tmp + 1, body, (size_t)len + 1); snprintf(out, 64, "%*.62s", w, tmp); }
     else snprintf(out, 64, "%*s", w, body);
 }
 
