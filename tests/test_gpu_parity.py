@@ -285,7 +285,7 @@ def test_zquad_complex_weights():
 
 
 @pytest.mark.parametrize("fused", ["chain", "fused", "cluster"])
-@pytest.mark.parametrize("kind,m,n,r,piv,nproc", [("c", 16, 51, 32, 2, 1), ("c", 64, 51, 32, 2, 8), ("c", 8, 25, 12, 3, 2), ("c", 5, 17, 8, 0, 1)])
+@pytest.mark.parametrize("kind,m,n,r,piv,nproc", [("c", 16, 51, 32, 2, 1), ("c", 64, 51, 32, 2, 8), ("c", 8, 25, 12, 3, 2), ("c", 5, 17, 8, 0, 1), ("c", 16, 33, 24, 0, 5)])
 def test_both_sweep_paths_bit_exact(monkeypatch, fused, kind, m, n, r, piv, nproc):
     """The three sweep implementations -- multi-kernel chain, one workgroup per group (ttx_fused.h), a cluster of
     workgroups per group (ttx_cluster.h) -- selected with TTX_SWEEP, each bit for bit against the oracle."""
@@ -480,7 +480,10 @@ def test_sweep_path_selection(monkeypatch):
 
 
 SHAPES = [(21, 17, 33, 3, 3), (9, 33, 48, 0, 2), (18, 3, 40, 0, 2), (15, 2, 3, 1, 1), (6, 9, 48, 1, 4), (4, 2, 6, 3, 2),
-          (13, 40, 40, 2, 3), (5, 7, 48, 3, 1), (19, 2, 33, 2, 1), (12, 40, 48, 3, 3), (20, 9, 40, 1, 4), (4, 33, 33, 2, 1)]
+          (13, 40, 40, 2, 3), (5, 7, 48, 3, 1), (19, 2, 33, 2, 1), (12, 40, 48, 3, 3), (20, 9, 40, 1, 4), (4, 33, 33, 2, 1),
+          # pivoting = 0 run into the noise floor: the acceptance test then depends on amax, which the piv = 0 branch of the
+          # reference (lib/dmrgg.f90:492-513) does NOT update with the two fibers it evaluates
+          (16, 33, 24, 0, 5), (7, 5, 40, 0, 1), (23, 16, 33, 0, 1)]
 
 
 @pytest.mark.parametrize("m,n,r,piv,ng", SHAPES, ids=[f"C{c[0]}_n{c[1]}_r{c[2]}_p{c[3]}_g{c[4]}" for c in SHAPES])

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             CST(9);
             mx = shm[0]; ab = sha[0]; bb = shv[0]; ix = shi[0];
             hcount++;
-            amax = fmax(amax, mx);
+            if (P.piv != 0) amax = fmax(amax, mx);           // the piv = 0 branch (:492-513) does not touch amax
             neval += nf;
             bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
             n_resid += resid ? 1 : 0;

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(FB) void k_sweep_fused(DevProb P, int dir, int nste
                 mx = fmax(mx, fabs(a));
             }
             mx = block_max(mx, sha);
-            amax = fmax(amax, mx);
+            if (P.piv != 0) amax = fmax(amax, mx);           // the piv = 0 branch (:492-513) does not touch amax
             neval += nf;
             bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
             n_resid += resid ? 1 : 0;

@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     }
     STAMP(gs, 1);   // 2: eval
     double mx = block_max(live ? fabs(a) : 0.0, sha);
-    if (tid == 0) atomic_max_pos(&gs.amax, mx);                               // :531 / :564
+    if (tid == 0 && mode != 1) atomic_max_pos(&gs.amax, mx);                  // :531 / :564 (the piv = 0 branch :492-513 does not touch amax)
     const int crs = cur.crs + 1;
     const int havecol = cur.havecol | (iscol ? 1 : 0), haverow = cur.haverow | (iscol ? 0 : 1);
     const int done = (mode == 1 || mode == 2) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
