@@ -1201,7 +1201,30 @@ static int svd_impl(ttx_engine *h, double tol, int rmax)
     std::vector<double> svh(RM);
     for (int k = d; k >= 2; k--) {                                      // lib/tt.f90:329-356
         const int mm = r[k - 1], n = h->n1[k], nn = n * r[k], kk = r[k - 2] * h->n1[k - 1];
-        if (mm > nn) return fail(TTX_EINVAL, "dtt_svd: core %d has more rows (%d) than columns (%d): not supported by the device path", k, mm, nn);
+        if (mm > nn) {
+            // tall unfolding (only possible for trains that do not come from a cross): A (mm x nn) = Q R, R = Ub S Vb^T
+            //   =>  A = (Q Ub S) Vb^T: Q Ub S goes into the previous core, Vb^T is the new core
+            hipLaunchKernelGGL(k_pack_core, g1((size_t)mm * nn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, mm, n, r[k], RM, SS, 0);
+            if ((rc = qr(h, mm, nn, h->Wa, Rm, tau))) return rc;        // Wa -> Q (mm x nn), Rm = R (nn x nn)
+            hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(1024), 0, h->stream, nn, nn, Rm, Vb, sv, perm, info, 1, tol, rmax);
+            int inf2[2];
+            HIPCHECK(hipMemcpyAsync(inf2, info, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipMemcpyAsync(svh.data(), sv, sizeof(double) * nn, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            const int rr = inf2[0];
+            s2 = 0.0; for (int j = 0; j < rr; j++) s2 += svh[j] * svh[j];
+            const double nrm = std::sqrt(s2);
+            if (nrm != 0.0) lognrm += std::log(nrm);
+            hipLaunchKernelGGL(k_take_cols, g1((size_t)nn * rr), dim3(256), 0, h->stream, nn, rr, Rm, nn, perm, sv, nrm != 0.0 ? 1.0 / nrm : 1.0, US);
+            gemm(h, mm, rr, nn, h->Wa, mm, US, nn, h->Wd, mm);          // Q Ub S  (mm x rr)
+            hipLaunchKernelGGL(k_pack_core, g1((size_t)kk * mm), dim3(256), 0, h->stream, core_dev(h, k - 1), h->Wb, r[k - 2], h->n1[k - 1], mm, RM, SS, 0);
+            gemm(h, kk, rr, mm, h->Wb, kk, h->Wd, mm, h->Wc, kk);
+            hipLaunchKernelGGL(k_unpack_core, g1((size_t)kk * rr), dim3(256), 0, h->stream, core_dev(h, k - 1), h->Wc, r[k - 2], h->n1[k - 1], rr, RM, SS, 0, 1.0);
+            hipLaunchKernelGGL(k_take_cols, g1((size_t)nn * rr), dim3(256), 0, h->stream, nn, rr, Vb, nn, perm, (const double *)nullptr, 1.0, Vs);
+            hipLaunchKernelGGL(k_unpack_core, g1((size_t)rr * nn), dim3(256), 0, h->stream, core_dev(h, k), Vs, rr, n, r[k], RM, SS, 1, 1.0);
+            r[k - 1] = rr;
+            continue;
+        }
         // A (mm x nn) = R1^T Q1^T with A^T = Q1 R1 ; R1^T = Ub S Vb^T  =>  A = Ub S (Q1 Vb)^T
         hipLaunchKernelGGL(k_pack_core, g1((size_t)mm * nn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, mm, n, r[k], RM, SS, 1);
         if ((rc = qr(h, nn, mm, h->Wa, Rm, tau))) return rc;            // Wa -> Q1 (nn x mm), Rm = R1 (mm x mm)
