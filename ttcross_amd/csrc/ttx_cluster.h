@@ -118,6 +118,10 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
     const int first = gs.first, last = gs.last, nbonds = last - first + 1;
     int *r = P.r + (size_t)g * (m + 2);
     const int VS = ((m + 7) & ~7) + 8;
+    // row stride of the value tables: 2*VS doubles would put every row on the same LDS banks (a multiple of 128 bytes), and
+    // a column half-step reads 32 DIFFERENT rows with one 16-byte load per lane -- a 32-way bank conflict on every load
+    // of the integrand chain.  Two extra doubles shift consecutive rows by 16 bytes: 8 rows tile the 32 banks.
+    const int RS = 2 * VS + 2;
     const int n1m = P.n[1];
     const int SL = RM * ((NM + NB - 1) / NB + 1);       // most fiber entries one block owns
     unsigned *ctr = P.cl_ctr + g;
@@ -128,8 +132,8 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
     // LDS carve-up
     double *par = dyn;
     double *XL = par + ((P.npar + 1) & ~1);            // RM rows x (VS node values, VS weight values)
-    double *XR = XL + (size_t)RM * 2 * VS;
-    double *acol = XR + (size_t)RM * 2 * VS;           // own slice of the column fiber
+    double *XR = XL + (size_t)RM * RS;
+    double *acol = XR + (size_t)RM * RS;           // own slice of the column fiber
     double *arow = acol + SL;                          // own slice of the row fiber
     double *resc = arow + SL;                          // residuals of the own column / row slice at the last half-step
     double *resr = resc + SL;                          // that computed them (reused by the append, roles A and B)
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 const int dc = CB / AL, dO = CB - dc * AL;
                 while (c < r0) {
                     const int ix = (o < p - 1) ? (int)Lt[(size_t)o * RM + c] : 1;
-                    XL[(size_t)c * 2 * VS + o] = par[ix - 1]; XL[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
+                    XL[(size_t)c * RS + o] = par[ix - 1]; XL[(size_t)c * RS + VS + o] = par[n1m + ix - 1];
                     c += dc; o += dO; if (o >= AL) { o -= AL; c++; }
                 }
             }
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 const int dc = CB / AR, dO = CB - dc * AR;
                 while (c < r2) {
                     const int ix = (o < m - p - 1) ? (int)Rt[(size_t)o * RM + c] : 1;
-                    XR[(size_t)c * 2 * VS + o] = par[ix - 1]; XR[(size_t)c * 2 * VS + VS + o] = par[n1m + ix - 1];
+                    XR[(size_t)c * RS + o] = par[ix - 1]; XR[(size_t)c * RS + VS + o] = par[n1m + ix - 1];
                     c += dc; o += dO; if (o >= AR) { o -= AR; c++; }
                 }
             }
@@ -279,13 +283,13 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         if (tid < r0) {                                // ascending sum over the left row (dims 1..p-1)
             double w = 1.0, wk = 1.0;
             auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
-            chain8v<false>(XL + (size_t)tid * 2 * VS, p - 1, wstep);
+            chain8v<false>(XL + (size_t)tid * RS, p - 1, wstep);
             pLw[tid] = w; pLk[tid] = wk;
         } else if (tid >= 64 && tid < 64 + r2) {       // descending sum over the right row (dims p+2..m)
             const int c = tid - 64;
             double v = 1.0, vk = 1.0;
             auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
-            chain8v<true>(XR + (size_t)c * 2 * VS, m - p - 1, vstep);
+            chain8v<true>(XR + (size_t)c * RS, m - p - 1, vstep);
             pRv[c] = v; pRk[c] = vk;
         }
         __syncthreads();
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             CST(3);
             const int i = (x - 1) % r0 + 1, j = (x - 1) / r0 + 1, k = (y - 1) % n2 + 1, q = (y - 1) / n2 + 1;
             lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
-            const double *rl = XL + (size_t)(i - 1) * 2 * VS, *rq = XR + (size_t)(q - 1) * 2 * VS;
+            const double *rl = XL + (size_t)(i - 1) * RS, *rq = XR + (size_t)(q - 1) * RS;
             const double f = f_ising_c4p(m, p - 1, rl, rl + VS, par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], rq, rq + VS, pRv[q - 1], pRk[q - 1], pLw[i - 1], pLk[i - 1]);
             ma = fmax(ma, fabs(f));
             CST(4);
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 double a;
                 if (iscol) {
                     const int i = u % r0, j = jlo + u / r0, t = i + r0 * j;
-                    const double *rl = XL + (size_t)i * 2 * VS, *rq = XR + (size_t)(qq - 1) * 2 * VS;
+                    const double *rl = XL + (size_t)i * RS, *rq = XR + (size_t)(qq - 1) * RS;
                     const double *c = Cp + i + (size_t)RM * j;
                     a = f_ising_c4p(m, p - 1, rl, rl + VS, par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], rq, rq + VS, pRv[qq - 1], pRk[qq - 1], pLw[i], pLk[i]);
                     fib[u] = a;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     }
                 } else {
                     const int k = klo + u % nk, q = u / nk, t = k + n2 * q;
-                    const double *rl = XL + (size_t)(ii - 1) * 2 * VS, *rq = XR + (size_t)q * 2 * VS;
+                    const double *rl = XL + (size_t)(ii - 1) * RS, *rq = XR + (size_t)q * RS;
                     const double *w = Wq + k + (size_t)NM * q;
                     a = f_ising_c4p(m, p - 1, rl, rl + VS, par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], rq, rq + VS, pRv[q], pRk[q], pLw[ii - 1], pLk[ii - 1]);
                     fib[u] = a;

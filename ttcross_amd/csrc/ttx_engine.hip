@@ -353,7 +353,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         NB = std::max(1, std::min(NB, TTX_CLMAX));
         while (NB > 1 && h->G * NB > prop.multiProcessorCount / 2) NB--;        // leave room for other processes on the card
         const size_t SL = (size_t)RM * ((NM + NB - 1) / NB + 1);
-        h->lds_cluster = sizeof(double) * (cfg->npar + 4 + 4 * RM * VS + 4 * SL + 2 * RM + 8) + sizeof(int) * 4 * (nlotmax + 4);
+        h->lds_cluster = sizeof(double) * (cfg->npar + 4 + 2 * RM * (2 * VS + 2) + 4 * SL + 2 * RM + 8) + sizeof(int) * 4 * (nlotmax + 4);
         if (h->lds_cluster + sizeof(double) * 2 * RM * RM <= 150 * 1024) { h->cluster_ldsinv = 1; h->lds_cluster += sizeof(double) * 2 * RM * RM; }
         {
             const size_t zk = sizeof(int) * ((size_t)h->nbmax * 2 * RM + 2 * h->nbmax + 4);

@@ -373,7 +373,7 @@ __device__ __forceinline__ void chain8v(const double *p, int n, STEP step)
 #pragma unroll
         for (int k = 7; k >= 0; k--) if (k < rem) step(x[k]);
     }
-#pragma unroll 2
+#pragma unroll 4
     for (int ch = 0; ch < nfull; ch++) {
         const int c = 8 * (DESC ? nfull - 1 - ch : ch);
         double x[8];
