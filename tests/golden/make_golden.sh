@@ -61,3 +61,6 @@ amdflang -O2 -fopenmp -I/opt/conda/include -Ioracle/_ref/mod tests/golden/ref_tt
   -o oracle/_ref/ref_ttio -L/opt/conda/lib -lmpifort -lmpi -lmkl_rt -Wl,-rpath,/opt/conda/lib -Wl,-rpath,/opt/rocm/lib/llvm/lib 2>/dev/null
 oracle/_ref/ref_ttio $G/ttio_5.tt $G/ttio_5.tt | grep -E "info|lm|^n|^r|checksum" > $G/ttio_5.txt
 rm -f *.mod
+# pivoting = 0 down to the noise floor (pins that the two fibers of lib/dmrgg.f90:492-513 do not enter amax)
+run1 ising C 16 33 24 0
+runp 5 C 16 33 24 0
