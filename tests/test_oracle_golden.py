@@ -20,6 +20,8 @@ EXACT_PREFIX = {
     "ising_C_6_33_20_2_np2": (17, 1e-14), "ising_C_6_33_20_2_np4": (20, 1e-14),
     "ising_C_16_51_32_2_np8": (18, 1e-13), "ising_C_64_51_32_2_np8": (7, 1e-13),
     "ising_D_8_33_10_2_np3": (10, 1e-14),
+    # pivoting = 0 down to the noise floor: acceptance depends on amax, which lib/dmrgg.f90:492-513 leaves alone
+    "ising_C_16_33_24_0": (24, 1e-14), "ising_C_16_33_24_0_np5": (17, 1e-13),
     "mvn_6_33_12_2": (8, 1e-3),      # inv_cov/det come from LAPACK in the reference; not converged at r=12
     "stdnorm_4_33_10_2": (2, 1e-13),
 }
