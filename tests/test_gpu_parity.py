@@ -151,7 +151,7 @@ def test_multi_process_bond_split(world, args):
     assert out.stdout.count(" OK") == world
 
 
-@pytest.mark.parametrize("name", ["ising_C_6_33_20_2", "ising_C_8_25_12_3", "ising_D_6_33_12_2", "ising_C_5_17_8_0"])
+@pytest.mark.parametrize("name", ["ising_C_6_33_20_2", "ising_C_8_25_12_3", "ising_D_6_33_12_2", "ising_C_5_17_8_0", "ising_C_16_33_24_0"])
 def test_fortran_dropin_driver_matches_reference_log(name):
     """The Fortran drop-in layer (ttcross_amd/fortran: modules named like the reference's, drivers with the
     reference's CLI) on the GPU against the golden stdout of the GENUINE reference."""
