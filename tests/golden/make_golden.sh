@@ -64,3 +64,7 @@ rm -f *.mod
 # pivoting = 0 down to the noise floor (pins that the two fibers of lib/dmrgg.f90:492-513 do not enter amax)
 run1 ising C 16 33 24 0
 runp 5 C 16 33 24 0
+run1 ising E 8 25 10 1
+run1 ising D 10 17 8 0
+runp 3 E 8 25 10 2
+run1 ising C 12 9 40 3

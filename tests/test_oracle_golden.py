@@ -22,6 +22,8 @@ EXACT_PREFIX = {
     "ising_D_8_33_10_2_np3": (10, 1e-14),
     # pivoting = 0 down to the noise floor: acceptance depends on amax, which lib/dmrgg.f90:492-513 leaves alone
     "ising_C_16_33_24_0": (24, 1e-14), "ising_C_16_33_24_0_np5": (17, 1e-13),
+    "ising_E_8_25_10_1": (10, 1e-14), "ising_D_10_17_8_0": (8, 1e-14), "ising_E_8_25_10_2_np3": (10, 1e-14),
+    "ising_C_12_9_40_3": (9, 1e-14),     # tiny modes: pivots reach rounding noise after 9 sweeps (37 in all)
     "mvn_6_33_12_2": (8, 1e-3),      # inv_cov/det come from LAPACK in the reference; not converged at r=12
     "stdnorm_4_33_10_2": (2, 1e-13),
 }
