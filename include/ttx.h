@@ -30,6 +30,7 @@ extern "C" {
 #define TTX_FUN_ISING 1    /* dfunc_ising_discr, test_crs_ising.f90:176-218 (par(2n+1) = 1/2/3 -> C/D/E) */
 #define TTX_FUN_STDNORM 2  /* integrand, test_crs_stdnorm.f90:154-170                                     */
 #define TTX_FUN_MVN 3      /* integrand -> mvn_pdf, test_crs_mvn.f90:156-172, lib/mvn_pdf.f90:63-83       */
+#define TTX_FUN_HOST 4     /* any user `fun` (lib/dmrgg.f90:18), evaluated on the HOST: ttx_set_integrand_host */
 
 typedef struct ttx_engine ttx_engine;
 
@@ -91,6 +92,18 @@ typedef struct ttx_transport {
     int (*allreduce)(void *ctx, double *buf, int64_t count, int op);
 } ttx_transport;
 int ttx_set_transport(ttx_engine *h, const ttx_transport *t);
+
+/* The reference's integrand callback, `double precision,external :: fun` called as fun(m, ind, n, par) (lib/dmrgg.f90:18,
+ * walked by dmrgg_fun :1053-1078): Fortran calling convention, everything by reference; ind and n are default integers.
+ * An engine created with fun_id = TTX_FUN_HOST evaluates every fiber through this function on the host -- each
+ * evaluating kernel first hands the multi-indices it needs to the host, the host calls `fun` from a pool of threads
+ * (TTX_HOST_THREADS, else OMP_NUM_THREADS, else the hardware; `fun` must be thread-safe, as under the reference's
+ * OpenMP loops), and the kernel continues with the values.  par is passed through untouched (may be NULL: the
+ * reference's `par` is optional).  The sweep logic, pivot search and factor updates stay on the device; results are
+ * those of the reference for the same `fun`.  pivoting = -1 is not available in this mode. */
+typedef double (*ttx_host_fun)(const int32_t *m, const int32_t *ind, const int32_t *n, const double *par);
+int ttx_set_integrand_host(ttx_engine *h, ttx_host_fun fun, const double *par);
+int64_t ttx_host_calls(const ttx_engine *h);                      /* calls of `fun` made by the last ttx_run */
 
 /* dtt_dmrgg itself: initial cross, sweeps until maxrank / 3 strikes, finalisation dtt_lua (lib/dmrgg.f90:151-1049) */
 int ttx_run(ttx_engine *h);
@@ -177,6 +190,12 @@ int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, cons
 /* lottery2 (lib/rnd.f90:105-126) with unit weights except zero at the listed 1-based positions */
 int ttx_k_lottery(int32_t device, int32_t npnt, int32_t m, int32_t n, int32_t nz, const int32_t *zcol,
                   const int32_t *zrow, uint64_t rngpos, int32_t *points /* [2*npnt] */);
+
+/* exp() of the integrands (test_crs_stdnorm.f90:168, lib/mvn_pdf.f90:82): the device code restates the run-time
+ * library's algorithm operation for operation (ttx_exp.h).  ttx_k_exp evaluates it on the device, ttx_exp_host the same
+ * source on the host (needs no GPU) -- both exist so that tests can pin it against libm bit for bit. */
+int ttx_k_exp(int32_t device, int64_t n, const double *x, double *out);
+int ttx_exp_host(int64_t n, const double *x, double *out);
 
 /* placement probe: the XCD (XCC_ID hardware register) on which each of `nblocks` workgroups of a plain 1-D launch
  * ran; the cluster sweep kernel relies on workgroups being dealt round-robin to the 8 XCDs */

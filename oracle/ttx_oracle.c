@@ -199,8 +199,10 @@ static double powi(double a, int b)
     return r;
 }
 
+static ttxo_user_fun g_user;        /* set by ttxo_dmrgg / ttxo_accchk from ttxo_problem.user (the oracle is single-threaded) */
 double ttxo_fun(int fun_id, int m, const int32_t *ind, const int32_t *n, const double *par, const double *aux)
 {
+    if (fun_id == TTXO_FUN_USER) { int32_t mm = m; return g_user(&mm, ind, n, par); }
     if (fun_id == TTXO_FUN_ISING) {
         /* test_crs_ising.f90:176-218 */
         const int n1 = n[0];
@@ -446,9 +448,12 @@ static void fmt_e(char *out, int w, int dgt, double v)
         char z[40]; memset(z, '0', (size_t)dgt); z[dgt] = 0;
         snprintf(body, sizeof body, ".%sE+00", z);
     }
-    int len = (int)strlen(body);
-    if (len + 1 <= w) { tmp[0] = '0'; memcpy(tmp + 1, body, (size_t)len + 1); snprintf(out, 64, "%*.62s", w, tmp); }
-    else snprintf(out, 64, "%*s", w, body);
+    /* Fortran Ew.d: the optional leading zero is dropped when the sign needs its place */
+    int len = (int)strlen(body), neg = (v < 0.0), k = 0;
+    if (neg) tmp[k++] = '-';
+    if (len + 1 + neg <= w) tmp[k++] = '0';
+    memcpy(tmp + k, body, (size_t)len + 1);
+    snprintf(out, 64, "%*.62s", w, tmp);
 }
 
 /* lib/dmrgg.f90:1169-1258 dtt_lua applied to an array of cores (arg or ttqq) of every rank.
@@ -729,6 +734,8 @@ int ttxo_dmrgg(const ttxo_problem *pb, ttxo_result *res)
     ctx_t cxs, *cx = &cxs;
     memset(cx, 0, sizeof *cx);
     memset(res, 0, sizeof *res);
+    g_user = pb->user;
+    if (pb->fun_id == TTXO_FUN_USER && !g_user) { fprintf(stderr, "ttx_oracle: TTXO_FUN_USER without a function\n"); return 1; }
     const int m = pb->d, P = pb->nproc < 1 ? 1 : pb->nproc;
     cx->pb = pb; cx->m = m; cx->n = pb->n; cx->nproc = P;
     if (P >= m) { fprintf(stderr, "nproc exceeds or equal dimension, cannot proceed\n"); return 1; } /* :114-117 */
@@ -1077,6 +1084,7 @@ void ttxo_accchk(const ttxo_problem *pb, const ttxo_result *res, int nlot, doubl
     const int m = pb->d;
     uint64_t pos = res->rngpos;
     int32_t ind[2050];
+    g_user = pb->user;
     double e1 = 0.0, e2 = 0.0, a1 = 0.0, a2 = 0.0;
     double *x = (double *)malloc(sizeof(double) * 4096), *z = (double *)malloc(sizeof(double) * 4096);
     for (int il = 0; il < nlot; il++) {

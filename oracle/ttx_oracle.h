@@ -27,8 +27,11 @@ extern "C" {
 enum {
     TTXO_FUN_ISING = 1,   /* dfunc_ising_discr, test_crs_ising.f90:176-218; par(2n+1) selects C/D/E   */
     TTXO_FUN_STDNORM = 2, /* integrand, test_crs_stdnorm.f90:154-170                                   */
-    TTXO_FUN_MVN = 3      /* integrand -> mvn_pdf, test_crs_mvn.f90:156-172, lib/mvn_pdf.f90:63-83     */
+    TTXO_FUN_MVN = 3,     /* integrand -> mvn_pdf, test_crs_mvn.f90:156-172, lib/mvn_pdf.f90:63-83     */
+    TTXO_FUN_USER = 4     /* the caller's own `fun` (lib/dmrgg.f90:18): ttxo_problem.user                */
 };
+/* the reference's callback interface fun(m, ind, n, par), Fortran convention (everything by reference) */
+typedef double (*ttxo_user_fun)(const int32_t *m, const int32_t *ind, const int32_t *n, const double *par);
 
 typedef struct ttxo_sweep_rec {
     int32_t it;        /* sweep number, 0 = initial cross                     */
@@ -60,6 +63,7 @@ typedef struct ttxo_problem {
     int32_t verbose;         /* 1: print the reference's per-sweep lines to stdout                   */
     const double *draws;     /* optional replay tape of uniform draws (NULL -> flang-compatible LCG)  */
     int64_t ndraws;
+    ttxo_user_fun user;      /* TTXO_FUN_USER: the integrand; par is handed to it untouched           */
 } ttxo_problem;
 
 typedef struct ttxo_result {

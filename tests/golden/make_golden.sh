@@ -2,7 +2,9 @@
 # Regenerates the golden logs in this directory from the GENUINE reference built by `make -C oracle ref`
 # (oracle/_ref/, from /root/reference; amdflang + MPICH + MKL sequential).  Only program OUTPUT is stored:
 # the per-sweep lines of lib/dmrgg.f90:971-1008 and the footer of the drivers, with the noisy `time:`
-# column blanked.  File name = driver arguments (+ _npP for P MPI ranks of the patched build).
+# column blanked.  File name = driver arguments (+ _npP for P MPI ranks).  The _npP logs come from the PATCHED multi-rank build
+# (oracle/make_ref_mpi.py re-inserts the right-going boundary exchange that lib/dmrgg.f90 lost; the unpatched fp64
+# source aborts on more than one rank), the others from the unmodified sources.
 set -e
 cd "$(dirname "$0")/../.."
 export MKL_THREADING_LAYER=SEQUENTIAL OMP_NUM_THREADS=1
@@ -22,6 +24,8 @@ run1 ising E 5 33 12 2
 run1 ising D 12 33 10 2
 run1 stdnorm 4 33 10 2
 run1 mvn 6 33 12 2
+# BASELINE config 4 at full size (about a minute on 8 threads; the result does not depend on the thread count)
+OMP_NUM_THREADS=8 run1 mvn 128 33 50 2
 runp 2 C 6 33 20 2
 runp 4 C 6 33 20 2
 runp 8 C 16 51 32 2

@@ -22,11 +22,18 @@ def parse_log(txt):
     return rows, value, neval
 
 
-def golden_cases():
+# golden logs whose oracle run takes minutes (single thread): compared through the stored oracle fixtures
+# tests/golden/oracle_*.npz (make_oracle_fixture.py) instead of a live oracle run
+LONG = {"mvn_128_33_50_2"}
+
+
+def golden_cases(include_long=False):
     """[(name, driver argv incl. nproc)] for every fixture made by make_golden.sh."""
     out = []
     for f in sorted(glob.glob(os.path.join(GOLDEN, "*.txt"))):
         b = os.path.basename(f)[:-4]
+        if b in LONG and not include_long:
+            continue
         if b.split("_")[0] not in ("ising", "stdnorm", "mvn"):      # driver logs only (not accchk_/ttops_/zquad_/flang_rng)
             continue
         t = b.split("_")

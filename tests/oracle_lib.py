@@ -18,7 +18,8 @@ class _Problem(ctypes.Structure):
     _fields_ = [("d", c_int32), ("n", POINTER(c_int32)), ("fun_id", c_int32), ("par", POINTER(c_double)), ("npar", c_int32),
                 ("aux", POINTER(c_double)), ("naux", c_int32), ("quadw", POINTER(c_double)), ("accuracy", c_double),
                 ("maxrank", c_int32), ("piv", c_int32), ("tru", c_double), ("has_tru", c_int32), ("nproc", c_int32),
-                ("mybonds", POINTER(c_int32)), ("verbose", c_int32), ("draws", POINTER(c_double)), ("ndraws", c_int64)]
+                ("mybonds", POINTER(c_int32)), ("verbose", c_int32), ("draws", POINTER(c_double)), ("ndraws", c_int64),
+                ("user", ctypes.c_void_p)]
 
 
 class _Result(ctypes.Structure):
@@ -56,7 +57,8 @@ def _ip(a):
     return a.ctypes.data_as(POINTER(c_int32)) if a is not None else None
 
 
-def dmrgg(n, fun_id, par, maxrank, piv=3, accuracy=None, quad=None, tru=None, aux=None, nproc=1, mybonds=None, accchk=0):
+def dmrgg(n, fun_id, par, maxrank, piv=3, accuracy=None, quad=None, tru=None, aux=None, nproc=1, mybonds=None, accchk=0, user=None):
+    """user: address of a C function double f(const int *m, const int *ind, const int *n, const double *par) for fun_id 4"""
     L = lib()
     n = np.ascontiguousarray(n, dtype=np.int32)
     par = np.ascontiguousarray(par, dtype=np.float64)
@@ -70,6 +72,7 @@ def dmrgg(n, fun_id, par, maxrank, piv=3, accuracy=None, quad=None, tru=None, au
     pb.maxrank, pb.piv = maxrank, piv
     pb.tru, pb.has_tru = (0.0 if tru is None else tru), (0 if tru is None else 1)
     pb.nproc, pb.mybonds, pb.verbose, pb.draws, pb.ndraws = nproc, _ip(mb), 0, None, 0
+    pb.user = user
     res = _Result()
     rc = L.ttxo_dmrgg(ctypes.byref(pb), ctypes.byref(res))
     if rc:

@@ -1,0 +1,152 @@
+"""GPU tests of the drop-in boundary: the user callback `fun` evaluated on the host, the Fortran
+modules with the reference's names, and -- where oracle/_ref holds them -- the reference's OWN drivers
+(test_crs_*.f90 compiled unchanged in the build container) linked against the engine."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import ROOT, fortran_exe
+from golden_util import GOLDEN, parse_log
+from ttcross_amd import drivers as D
+from ttcross_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def userfun():
+    """tests/userfun.c -> shared object; returns (CDLL, address of ttx_test_userfun)."""
+    bdir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    so = os.path.join(bdir, "libuserfun.so")
+    src = os.path.join(ROOT, "tests", "userfun.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", src, "-o", so, "-lm"], check=True)
+    lib = ctypes.CDLL(so)
+    return lib, ctypes.cast(lib.ttx_test_userfun, ctypes.c_void_p).value
+
+
+def _user_setup(d, n):
+    x, w = D.lgwt(n)
+    par = np.concatenate([0.5 * (x + 1.0), 0.5 * w])          # nodes and weights on [0,1] (test_crs_box.inc with a=0, b=1)
+    return dict(n=[n] * d, par=par, quad=[par[n:].copy()] * d, acc=500 * D.EPS)
+
+
+@pytest.mark.parametrize("d,n,r,piv,nproc", [(5, 17, 10, 2, 1), (6, 13, 8, 1, 3), (4, 9, 6, 0, 1), (8, 11, 7, 3, 2)])
+def test_host_callback_bit_exact_vs_oracle(userfun, d, n, r, piv, nproc):
+    """An integrand that is not built in: the engine asks the host for every fiber (ttx_set_integrand_host), the oracle
+    calls the same C function -- tapes, evaluation counts, per-sweep values, cores and integral must be identical."""
+    _, addr = userfun
+    s = _user_setup(d, n)
+    tt = E.TTCross(s["n"], E.TTX_FUN_HOST, [], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], nproc=nproc)
+    tt.set_integrand_host(addr, s["par"]).run()
+    oo = O.dmrgg(s["n"], 4, s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], nproc=nproc, user=addr)
+    assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d])
+    assert [a["neval"] for a in tt.sweeps()] == [b["neval"] for b in oo["sweeps"]]
+    assert [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]]
+    assert [a["amax"] for a in tt.sweeps()] == [b["amax"] for b in oo["sweeps"]]
+    assert tt.neval == oo["neval"] and tt.host_calls >= tt.neval      # groups evaluate the initial samples redundantly
+    assert np.array_equal(tt.ranks(), oo["r"])
+    assert all(np.array_equal(tt.core(k), oo["cores"][k - 1]) for k in range(1, d + 1))
+    assert tt.quad(s["quad"]) == oo["value"]
+
+
+def test_host_callback_accchk(userfun):
+    _, addr = userfun
+    s = _user_setup(5, 17)
+    tt = E.TTCross(s["n"], E.TTX_FUN_HOST, [], 10, pivoting=2, accuracy=s["acc"], quad=s["quad"])
+    tt.set_integrand_host(addr, s["par"]).run()
+    oo = O.dmrgg(s["n"], 4, s["par"], 10, piv=2, accuracy=s["acc"], quad=s["quad"], user=addr, accchk=3000)
+    got = tt.accchk(3000)
+    for k in ("einf", "efro", "ainf", "afro"):
+        assert got[k] == oo["accchk"][k], k
+    assert np.array_equal(got["pivot"], oo["accchk"]["pivot"])
+
+
+def test_host_callback_needs_the_function():
+    s = _user_setup(4, 9)
+    tt = E.TTCross(s["n"], E.TTX_FUN_HOST, [], 6, pivoting=1, accuracy=s["acc"])
+    with pytest.raises(E.TTXError, match="ttx_set_integrand_host"):
+        tt.run()
+    with pytest.raises(E.TTXError, match="pivoting = -1"):
+        E.TTCross(s["n"], E.TTX_FUN_HOST, [], 6, pivoting=-1)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_fortran_driver_with_user_callback(userfun, mode, monkeypatch):
+    """ttcross_amd/fortran/test_crs_user.f90: `call dtt_dmrgg(tt, fun, ...)` with a callback of the driver's own --
+    mode 1 without `par` (the callback reads module data, as calc_coefficient of test_crs_coscoeff.f90:186 does),
+    mode 2 also without `maxrank` (lib/dmrgg.f90:19-21: both are optional).  Per-sweep lines against the oracle
+    running the C twin of the callback."""
+    _, addr = userfun
+    d, n, r, piv = 5, 17, 9, 2
+    exe = fortran_exe("test_crs_user")
+    if mode == 2:
+        monkeypatch.setenv("TTX_MAXRANK_DEFAULT", "12")
+        r = 12
+    p = subprocess.run([exe, str(d), str(n), str(r), str(piv), str(mode)], capture_output=True, text=True, timeout=300, env=dict(os.environ))
+    assert p.returncode == 0, p.stdout + p.stderr
+    rows, val, nev = parse_log(p.stdout)
+    s = _user_setup(d, n)
+    oo = O.dmrgg(s["n"], 4, s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], user=addr)
+    assert len(rows) == len(oo["sweeps"]) and nev == oo["neval"]
+    for a, b in zip(rows, oo["sweeps"]):
+        assert a["neval"] == b["neval"] and abs(a["val"] - b["val"]) <= 1e-13 * abs(b["val"])
+    assert abs(val - oo["value"]) <= 1e-15 * abs(val)
+
+
+def test_fortran_tt_generics():
+    """Host-side generics of the drop-in tt_lib and mat_lib; `b = a` deep copy with disjoint ownership."""
+    p = subprocess.run([fortran_exe("test_tt_generics")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = {ln.split()[0]: ln.split()[1:] for ln in p.stdout.splitlines() if ln.strip()}
+    n = [2, 3, 4, 5]
+    tot = np.prod([0.5 * (k + 1) * n[k] for k in range(4)])          # every core k is the constant k/2: rank-1 train
+    elem = np.prod([0.5 * (k + 1) for k in range(4)])
+    assert [float(v) for v in out["copy_independent"]] == [1.0, 7.0]
+    assert float(out["numel"][0]) == 120.0 and int(out["memory"][0]) == 14
+    assert abs(float(out["sumall"][0]) - tot) < 1e-9
+    assert [int(v) for v in out["plus_ranks"]] == [1, 2, 2, 2, 1]
+    assert abs(float(out["plus_sumall"][0]) - 2 * tot) < 1e-9 and abs(float(out["mul_sumall"][0]) - 3 * tot) < 1e-9
+    assert abs(float(out["tijk"][0]) - elem) < 1e-12 and abs(float(out["elem"][0]) - elem) < 1e-12
+    assert abs(float(out["value0"][0]) - elem) < 1e-12
+    nrm = elem * np.sqrt(120.0)
+    assert abs(float(out["norm"][0]) - nrm) < 1e-5 and abs(float(out["lognrm"][0]) - np.log10(nrm)) < 1e-5
+    assert abs(float(out["dot"][0]) - nrm ** 2) < 1e-4
+    assert [int(v) for v in out["svd_ranks"]] == [1, 1, 1, 1, 1] and abs(float(out["svd_norm"][0]) - 2 * nrm) < 1e-5
+    assert float(out["zeros_sumall"][0]) == 0.0 and abs(float(out["copy_sumall"][0]) - tot) < 1e-9
+    assert float(out["matinv_err"][0]) < 1e-14 and float(out["svd_err"][0]) < 1e-13 and int(out["chop"][0]) == 2
+    assert "dealloc_ok" in out
+
+
+REF_DROPIN = [("ising", "ising_C_6_33_20_2"), ("ising", "ising_D_6_33_12_2"), ("ising", "ising_C_16_33_24_0"),
+              ("stdnorm", "stdnorm_4_33_10_2"), ("mvn", "mvn_6_33_12_2")]
+
+
+@pytest.mark.parametrize("drv,name", REF_DROPIN, ids=[c[1] for c in REF_DROPIN])
+def test_reference_drivers_unchanged_on_the_engine(drv, name):
+    """The reference's OWN test_crs_{ising,stdnorm,mvn}.f90, compiled UNCHANGED in the build container against the drop-in
+    modules and linked with libttx.so (oracle/Makefile target `dropin`, binaries in oracle/_ref/ -- the sources stay
+    behind), run on the GPU against the golden logs of the genuine reference."""
+    exe = os.path.join(ROOT, "oracle", "_ref", f"dropin_test_crs_{drv}")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_test_crs_* not built (needs /root/reference + amdflang: make -C oracle dropin)")
+    argv = name.split("_")[1:]
+    p = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    g_rows, g_val, g_nev = parse_log(open(os.path.join(GOLDEN, name + ".txt")).read())
+    o_rows, o_val, o_nev = parse_log(p.stdout)
+    assert len(g_rows) == len(o_rows)
+    need = {"ising": len(g_rows), "stdnorm": 2, "mvn": 8}[drv]        # as the oracle against the same logs (test_oracle_golden.py)
+    k = 0
+    for a, b in zip(g_rows, o_rows):
+        if a["erank"] == b["erank"] and a["neval"] == b["neval"] and abs(a["val"] - b["val"]) <= 2e-13 * abs(a["val"]):
+            k += 1
+        else:
+            break
+    assert k >= need, f"only {k} leading sweeps match the reference (need {need})"
+    assert abs(g_val - o_val) <= {"ising": 1e-14, "stdnorm": 1e-13, "mvn": 1e-3}[drv] * abs(g_val)

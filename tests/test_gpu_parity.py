@@ -1,8 +1,7 @@
 """GPU parity tests: the HIP engine (through the C-ABI of libttx.so) against the CPU oracle on the same
 inputs.  Integer/index work (pivot tapes, ranks, evaluation counts) must be IDENTICAL; floating point must
-be bit-identical for the Ising integrands (same operation order, no FMA contraction, IEEE division) and
-within a stated relative tolerance for exp-based integrands (device exp differs from glibc's in the last
-ulp, which may also steer near-tie pivots differently)."""
+be bit-identical for ALL integrands (same operation order, no FMA contraction, IEEE division; the exp of the
+stdnorm / mvn integrands restates the run-time library's algorithm operation for operation, ttx_exp.h)."""
 import numpy as np
 import pytest
 
@@ -70,16 +69,120 @@ def test_bond_groups_bit_exact(kind, m, n, r, piv, nproc):
     assert tt.quad(s["quad"]) == oo["value"]
 
 
-@pytest.mark.parametrize("kind,d,n,r,piv", [("stdnorm", 4, 33, 10, 2), ("mvn", 6, 33, 12, 2)])
-def test_exp_integrands(kind, d, n, r, piv):
+def _assert_identical(tt, oo, cores=True):
+    """tapes, per-sweep records, ranks, evaluation count (and finalised cores) of the engine == the oracle's, bit for bit"""
+    gs, os_ = tt.sweeps(), oo["sweeps"]
+    assert len(gs) == len(os_)
+    assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d]), "pivot tapes differ"
+    for a, b in zip(gs, os_):
+        assert a["neval"] == b["neval"] and a["erank"] == b["erank"], f"sweep {a['it']}"
+        assert a["val"] == b["val"], f"sweep {a['it']}: val {a['val']!r} vs {b['val']!r}"
+        assert a["amax"] == b["amax"] and a["pivotmax"] == b["pivotmax"], f"sweep {a['it']}"
+    assert tt.neval == oo["neval"] and np.array_equal(tt.ranks(), oo["r"])
+    if cores:
+        for k in range(1, tt.d + 1):
+            assert np.array_equal(tt.core(k), oo["cores"][k - 1]), f"core {k} differs"
+
+
+def test_exp_device_is_the_runtime_libm():
+    """The integrands' exp on the device (ttx_exp.h) against the host's libm, bit for bit -- the arguments the
+    stdnorm / mvn integrands produce (0 down to the subnormal tail), plus the special values."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.exp.restype = ctypes.c_double
+    libm.exp.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(11)
+    x = np.concatenate([-rng.random(200000) * 800.0, -745.2 + rng.random(50000) * 40.0, (rng.random(50000) - 0.5) * 1400.0,
+                        (rng.random(20000) - 0.5) * 1e-9, [0.0, -0.0, 709.78, 710.0, -745.13, -745.14, -746.0, float("inf"), -float("inf")]])
+    got = E.k_exp(x)
+    want = np.array([libm.exp(v) for v in x])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+EXP_CASES = [("stdnorm", 4, 33, 10, 2, 1), ("mvn", 6, 33, 12, 2, 1), ("stdnorm", 7, 17, 8, 1, 3), ("mvn", 9, 17, 10, 3, 2),
+             ("mvn", 5, 9, 6, 0, 1), ("stdnorm", 5, 9, 5, -1, 1), ("mvn", 24, 17, 12, 2, 4)]
+
+
+@pytest.mark.parametrize("kind,d,n,r,piv,nproc", EXP_CASES, ids=[f"{c[0]}{c[1]}_n{c[2]}_r{c[3]}_p{c[4]}_np{c[5]}" for c in EXP_CASES])
+def test_exp_integrands_bit_exact(kind, d, n, r, piv, nproc):
+    """stdnorm / mvn: with the run-time library's exp restated on the device (ttx_exp.h) these runs are bit-identical to
+    the oracle like the Ising ones -- tapes, every per-sweep record, cores, integral (round 1 could only assert 1e-9 on
+    the integral: one last-ulp difference in exp re-routes the pivots of these symmetric integrands)."""
     s = D.box_setup(kind, d, n)
     if kind == "mvn":
         s["aux"] = O.mvn_init(d)
-    tt, oo = _run_both(s, r, piv)
-    gv, ov = tt.quad(s["quad"]), oo["value"]
-    assert abs(gv - ov) <= 1e-9 * abs(ov)
-    g0, o0 = tt.sweeps()[0], oo["sweeps"][0]
-    assert g0["neval"] == o0["neval"] and abs(g0["val"] - o0["val"]) <= 1e-12 * abs(o0["val"])
+    tt, oo = _run_both(s, r, piv, nproc=nproc)
+    _assert_identical(tt, oo)
+    assert tt.quad(s["quad"]) == oo["value"]
+
+
+@pytest.mark.parametrize("name,need", [("stdnorm_4_33_10_2", 2), ("mvn_6_33_12_2", 8)])
+def test_exp_integrands_leading_sweeps_vs_reference_log(name, need):
+    """The GPU path against the golden logs of the GENUINE reference, as tests/test_oracle_golden.py asserts for the oracle:
+    `need` leading sweeps identical in (erank, n_evals) and to 2e-13 in val; then the noise floor decides near-ties
+    (the reference inverts the covariance with LAPACK and sums with MKL)."""
+    import os
+    from golden_util import GOLDEN, parse_log
+    kind, d, n, r, piv = name.split("_")[0], *[int(v) for v in name.split("_")[1:]]
+    s = D.box_setup(kind, d, n)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"]).run()
+    g_rows, g_val, _ = parse_log(open(os.path.join(GOLDEN, name + ".txt")).read())
+    rows = tt.sweeps()
+    assert len(rows) == len(g_rows)
+    k = 0
+    for a, b in zip(g_rows, rows):
+        if a["erank"] == round(b["erank"], 1) and a["neval"] == b["neval"] and abs(a["val"] - b["val"]) <= 2e-13 * abs(a["val"]):
+            k += 1
+        else:
+            break
+    assert k >= need, f"only {k} leading sweeps match the reference (need {need})"
+    assert abs(tt.quad(s["quad"]) - g_val) <= (1e-13 if kind == "stdnorm" else 1e-3) * abs(g_val)
+
+
+@pytest.mark.parametrize("nproc", [1, 4])
+def test_config4_mvn_128_full_size_vs_oracle_fixture(nproc):
+    """BASELINE config 4 at FULL size (test_crs_mvn 128 33 50 2; d = 128, n = 33, r = 50) through the C-ABI, against the
+    per-sweep fixture of the oracle made in the build container (tests/golden/make_oracle_fixture.py; the oracle needs
+    minutes, so it does not run here): nproc = 1, the reference's own decomposition, and nproc = 4, the configuration's
+    four bond groups.  Everything the fixture holds must be IDENTICAL: 49 sweeps of tapes, erank, n_evals, val, amax,
+    pivotmax, the final ranks and the integral."""
+    import os
+    from golden_util import GOLDEN
+    f = np.load(os.path.join(GOLDEN, f"oracle_mvn_128_33_50_2_np{nproc}.npz"))
+    s = D.box_setup("mvn", 128, 33)
+    s["aux"] = O.mvn_init(128)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], 50, pivoting=2, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=nproc).run()
+    rows = tt.sweeps()
+    assert len(rows) == len(f["it"]) == 50
+    assert np.array_equal(tt.tapes()[:, 1:tt.d].astype(np.int16), f["tapes"][:, 1:tt.d]), "pivot tapes differ"
+    assert [a["neval"] for a in rows] == f["neval"].tolist()
+    assert [a["erank"] for a in rows] == f["erank"].tolist()
+    assert [a["val"] for a in rows] == f["val"].tolist()
+    assert [a["amax"] for a in rows] == f["amax"].tolist() and [a["pivotmax"] for a in rows] == f["pivotmax"].tolist()
+    assert np.array_equal(tt.ranks(), f["r"]) and tt.neval == int(f["total_neval"])
+    assert tt.quad(s["quad"]) == float(f["value"])
+
+
+def test_config4_mvn_128_full_size_vs_reference_log():
+    """The same run (nproc = 1) against the golden log of the GENUINE reference (oracle/_ref/test_crs_mvn 128 33 50 2).
+    The integrand is symmetric under permutations of the dimensions, so exact ties between symmetric pivot candidates are
+    broken by rounding alone: the reference (LAPACK inverse, MKL sums) and this engine part ways in n_evals at sweep 1 and
+    the run is far from converged at r = 50 (1.2 correct digits).  What must agree: the number of sweeps, erank over the
+    first 10 sweeps, val to 1e-9 over the first 6, n_evals to 1 % in every sweep, the final value to 5 %."""
+    import os
+    from golden_util import GOLDEN, parse_log
+    g_rows, g_val, g_nev = parse_log(open(os.path.join(GOLDEN, "mvn_128_33_50_2.txt")).read())
+    s = D.box_setup("mvn", 128, 33)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], 50, pivoting=2, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"]).run()
+    rows = tt.sweeps()
+    assert len(rows) == len(g_rows) == 50
+    for k, (a, b) in enumerate(zip(g_rows, rows)):
+        if k < 10:
+            assert a["erank"] == round(b["erank"], 1), f"sweep {k}"
+        if k < 6:
+            assert abs(a["val"] - b["val"]) <= 1e-9 * abs(a["val"]), f"sweep {k}"
+        assert abs(a["neval"] - b["neval"]) <= 0.01 * a["neval"], f"sweep {k}"
+    assert abs(tt.quad(s["quad"]) - g_val) <= 0.05 * abs(g_val)
 
 
 def test_k2_residual_argmax_bit_exact():
@@ -112,11 +215,11 @@ def test_k1_integrands_vs_oracle():
         assert np.array_equal(g, o)
     s = D.box_setup("stdnorm", 5, 33)
     ind = rng.integers(1, 34, size=(300, 5)).astype(np.int32)
-    assert np.allclose(E.k_eval(E.TTX_FUN_STDNORM, s["n"], s["par"], ind), O.fun(2, s["n"], s["par"], ind), rtol=1e-14, atol=0)
+    assert np.array_equal(E.k_eval(E.TTX_FUN_STDNORM, s["n"], s["par"], ind), O.fun(2, s["n"], s["par"], ind))
     s = D.box_setup("mvn", 6, 33)
     aux = O.mvn_init(6)
     ind = rng.integers(1, 34, size=(300, 6)).astype(np.int32)
-    assert np.allclose(E.k_eval(E.TTX_FUN_MVN, s["n"], s["par"], ind, aux=aux), O.fun(3, s["n"], s["par"], ind, aux=aux), rtol=1e-13, atol=0)
+    assert np.array_equal(E.k_eval(E.TTX_FUN_MVN, s["n"], s["par"], ind, aux=aux), O.fun(3, s["n"], s["par"], ind, aux=aux))
 
 
 def test_lottery_bit_exact():
@@ -159,9 +262,8 @@ def test_fortran_dropin_driver_matches_reference_log(name):
     import subprocess
     from golden_util import GOLDEN, parse_log
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "ttcross_amd", "fortran", "build", "test_crs_ising")
-    if not os.path.exists(exe):
-        pytest.skip("Fortran layer not built (needs amdflang)")
+    from conftest import fortran_exe
+    exe = fortran_exe("test_crs_ising")
     argv = name.split("_")[1:]
     out = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -435,9 +537,8 @@ def test_fortran_ttio_dropin(tmp_path):
     from golden_util import GOLDEN
     from ttcross_amd import ttio
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "ttcross_amd", "fortran", "build", "test_ttio")
-    if not os.path.exists(exe):
-        pytest.skip("Fortran layer not built (needs amdflang)")
+    from conftest import fortran_exe
+    exe = fortran_exe("test_ttio")
     gold = os.path.join(GOLDEN, "ttio_5.tt")
     p = subprocess.run([exe, gold, str(tmp_path / "copy.tt"), str(tmp_path / "ones.tt")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
@@ -531,9 +632,8 @@ def test_fortran_chf_dropin_matches_python_driver():
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "ttcross_amd", "fortran", "build", "test_crs_chf")
-    if not os.path.exists(exe):
-        pytest.skip("Fortran layer not built (needs amdflang)")
+    from conftest import fortran_exe
+    exe = fortran_exe("test_crs_chf")
     p = subprocess.run([exe, "5", "17", "8", "2"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     got = {int(ln.split()[2]): complex(float(ln.split()[3]), float(ln.split()[4])) for ln in p.stdout.splitlines() if ln.startswith("computed value:")}

@@ -68,6 +68,10 @@ struct GroupState {
     Partial Pt[2][TTX_MAXPART];
 };
 
+// partial result of one workgroup of the lottery kernel (candidates [b*CH, (b+1)*CH) of a group): the block's first
+// arg-max of |residual| with its candidate (i,j,k,q), and the block's max |f|; the last block to finish combines them
+struct LotPart { double ab, bv, ma; int il, i, j, k, q, pad; };
+
 #define TTX_CLMAX 16            // most workgroups one bond group's cluster may have
 struct ClPart { double ab, bb, mx; int ix, pad; };
 
@@ -122,6 +126,18 @@ struct DevProb {
     int *rq;                       // [G][d+2] ranks at the end of the sweep, for the forked quadrature
     double accuracy; int maxrank;
     // cluster sweep kernel (ttx_cluster.h): per-group barrier counters, abort flag, per-block partial arg-max records
+    // lottery spread over several workgroups per group (heavy integrands): [G][lot_nb] partials + arrival counters [G]
+    struct LotPart *lotp;
+    unsigned *lot_ctr;
+    int lot_nb;
+    // host-evaluated integrand (TTX_FUN_HOST, the reference's user callback `fun`, lib/dmrgg.f90:18): every kernel that
+    // evaluates runs twice.  Pass 1 (hostpass = 1) writes the multi-index of each point it needs to hidx[slot][d], raises
+    // hreq[slot] and stops before any side effect; the host calls `fun`; pass 2 (hostpass = 2) reads hval[slot].
+    // All three arrays live in pinned host memory; a group's slots are [g*HS, (g+1)*HS).
+    int hostpass, HS;
+    short *hidx;
+    double *hval;
+    unsigned char *hreq;
     unsigned *cl_ctr;              // [G]
     int *cl_abort;                 // [1]
     struct ClPart *cl_part;        // [2][G][TTX_CLMAX]

@@ -13,7 +13,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -119,7 +123,106 @@ struct ttx_engine {
     int cluster = 0;                    // workgroups per bond group of the cluster sweep kernel (ttx_cluster.h); 0: not used
     size_t lds_cluster = 0;
     int *h_abort = nullptr;             // pinned, device-visible: the cluster kernel's barrier-timeout flag
+    // user integrand evaluated on the host (TTX_FUN_HOST): see DevProb::hostpass
+    ttx_host_fun hfun = nullptr;
+    const double *hfun_par = nullptr;   // the caller's par(*), passed through untouched
+    size_t HS = 0;
+    int64_t host_calls = 0;
 };
+
+// ---- worker threads for the host integrand (the reference evaluates `fun` inside !$OMP PARALLEL DO regions,
+//      lib/dmrgg.f90:169,222,455,520,553; `fun` must be thread-safe there and here) ----------------------------
+namespace {
+class HostPool {
+  public:
+    static HostPool &get() { static HostPool p; return p; }
+    int threads() const { return (int)workers.size() + 1; }
+    // fn(i) for i in [0, n): the calling thread takes part; returns when all are done
+    void run(size_t n, const std::function<void(size_t)> &fn)
+    {
+        if (n == 0) return;
+        if (workers.empty() || n < 32) { for (size_t i = 0; i < n; i++) fn(i); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &fn; total = n; next = 0; pending = workers.size(); gen++;
+        }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu);
+        done.wait(lk, [&] { return pending == 0; });
+        job = nullptr;
+    }
+  private:
+    HostPool()
+    {
+        int nt = 0;
+        if (const char *e = getenv("TTX_HOST_THREADS")) nt = atoi(e);
+        else if (const char *e2 = getenv("OMP_NUM_THREADS")) nt = atoi(e2);
+        if (nt <= 0) nt = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        for (int t = 1; t < nt; t++) workers.emplace_back([this] { loop(); });
+    }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; gen++; }
+        cv.notify_all();
+        for (auto &w : workers) w.join();
+    }
+    void work()
+    {
+        for (;;) {
+            size_t lo, hi;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (next >= total) return;
+                lo = next; hi = std::min(total, lo + std::max<size_t>(1, total / (8 * (workers.size() + 1)))); next = hi;
+            }
+            for (size_t i = lo; i < hi; i++) (*job)(i);
+        }
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                if (quit) return;
+            }
+            work();
+            { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) done.notify_all(); }
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv, done;
+    const std::function<void(size_t)> *job = nullptr;
+    size_t total = 0, next = 0, pending = 0;
+    unsigned long long gen = 0;
+    bool quit = false;
+};
+}
+
+// after the index pass of a kernel: wait for it, call the user's function for every requested slot, clear the requests
+static int host_eval(ttx_engine *h)
+{
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipGetLastError());
+    DevProb &P = h->P;
+    const size_t nslot = (size_t)h->G * h->HS;
+    std::vector<uint32_t> todo;
+    for (size_t s = 0; s < nslot; s++) if (P.hreq[s]) { todo.push_back((uint32_t)s); P.hreq[s] = 0; }
+    const int32_t d = h->d;
+    const int32_t *nn = h->n1.data() + 1;
+    HostPool::get().run(todo.size(), [&](size_t i) {
+        int32_t ind[2048];
+        const short *row = P.hidx + (size_t)todo[i] * d;
+        for (int k = 0; k < d; k++) ind[k] = row[k];
+        P.hval[todo[i]] = h->hfun(&d, ind, nn, h->hfun_par);
+    });
+    h->host_calls += (int64_t)todo.size();
+    return TTX_OK;
+}
 
 template <class T>
 static int dev_alloc(ttx_engine *h, T **p, size_t count)
@@ -156,12 +259,17 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
 {
     if (!out || !cfg) return fail(TTX_EINVAL, "ttx_create: null argument");
     *out = nullptr;
+    if (!cfg->n) return fail(TTX_EINVAL, "ttx_create: mode sizes missing");
     if (cfg->d < 2) return fail(TTX_EINVAL, "dtt_dmrgg: l,m: 1 %d", cfg->d);
     if (cfg->maxrank < 1 || cfg->maxrank > 128) return fail(TTX_EINVAL, "ttx_create: maxrank must be in 1..128 (got %d)", cfg->maxrank);
     if (cfg->pivoting < -1) return fail(TTX_EINVAL, "dtt_dmrgg: unknown pivoting: %d", cfg->pivoting);   // lib/dmrgg.f90:590-592
     if (2 * cfg->pivoting + 2 > TTX_MAXH) return fail(TTX_EINVAL, "dtt_dmrgg: pivoting %d too large", cfg->pivoting);
-    if (!(nofun && cfg->fun_id == 0) && (cfg->fun_id < 1 || cfg->fun_id > 3)) return fail(TTX_EINVAL, "ttx_create: unknown fun_id %d", cfg->fun_id);
+    if (!(nofun && cfg->fun_id == 0) && (cfg->fun_id < 1 || cfg->fun_id > 4)) return fail(TTX_EINVAL, "ttx_create: unknown fun_id %d", cfg->fun_id);
     if (cfg->npar < 0 || (cfg->npar > 0 && !cfg->par)) return fail(TTX_EINVAL, "ttx_create: par missing");
+    if (cfg->fun_id == TTX_FUN_ISING && (cfg->npar < 2 * cfg->n[0] + 1)) return fail(TTX_EINVAL, "ttx_create: the Ising integrand needs par(1:2n+1) (nodes, weights, id)");
+    if ((cfg->fun_id == TTX_FUN_STDNORM || cfg->fun_id == TTX_FUN_MVN) && cfg->npar < cfg->n[0]) return fail(TTX_EINVAL, "ttx_create: the integrand needs the nodes par(1:n)");
+    if (cfg->fun_id == TTX_FUN_HOST && cfg->pivoting < 0) return fail(TTX_EINVAL, "ttx_create: pivoting = -1 is not available with a host integrand");
+    if (cfg->fun_id == TTX_FUN_HOST && cfg->d > 2048) return fail(TTX_EINVAL, "ttx_create: host integrand: at most 2048 dimensions (tt_size)");
     const int W = cfg->world_size < 1 ? 1 : cfg->world_size;
     const int nproc = std::max(cfg->nproc < 1 ? 1 : cfg->nproc, 1);
     if (nproc >= cfg->d) return fail(TTX_EINVAL, "nproc exceeds or equal dimension, cannot proceed");   // lib/dmrgg.f90:114-117
@@ -375,6 +483,30 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         }
     }
     if (h->lds_half > 160 * 1024 || h->lds_lot > 120 * 1024) { ttx_destroy(h); return fail(TTX_EINVAL, "problem too large for LDS staging (d*maxrank)"); }
+    {   // lottery: one wave of candidates per workgroup where one evaluation is a long dependent chain (Ising D/E, mvn)
+        const bool heavy = (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1) || cfg->fun_id == TTX_FUN_MVN;
+        const int nlotmax = 2 * h->RM + 2 * NM;
+        P.lot_nb = 1;
+        if (heavy && !(getenv("TTX_LOTTERY_NB") && atoi(getenv("TTX_LOTTERY_NB")) == 1)) P.lot_nb = std::min((nlotmax + 63) / 64, 64);
+        if (P.lot_nb > 1 && (nlotmax + P.lot_nb - 1) / P.lot_nb > 64) P.lot_nb = 1;      // more candidates than 64 blocks x 64: keep one block
+        LotPart *lp; unsigned *lc;
+        rc = dev_alloc(h, &lp, (size_t)h->G * P.lot_nb); if (rc) { ttx_destroy(h); return rc; }
+        rc = dev_alloc(h, &lc, (size_t)h->G); if (rc) { ttx_destroy(h); return rc; }
+        P.lotp = lp; P.lot_ctr = lc;
+    }
+    if (cfg->fun_id == TTX_FUN_HOST) {
+        // slots of one group: the largest point set any evaluating kernel asks for in one launch
+        int nn = h->n1[1];
+        for (int k = 2; k <= d; k++) nn = std::min(nn, h->n1[k]);
+        const size_t snum = (size_t)std::max(8, nproc);
+        h->HS = std::max<size_t>({(size_t)h->RM * NM, (size_t)nn * snum, (size_t)h->NC * NM, (size_t)2 * h->RM + 2 * NM, (size_t)2 * NM, (size_t)256});
+        const size_t nslot = (size_t)h->G * h->HS;
+        HIPCHECK(hipHostMalloc((void **)&P.hidx, sizeof(short) * nslot * d));
+        HIPCHECK(hipHostMalloc((void **)&P.hval, sizeof(double) * nslot));
+        HIPCHECK(hipHostMalloc((void **)&P.hreq, nslot));
+        memset(P.hreq, 0, nslot); memset(P.hval, 0, sizeof(double) * nslot);
+        P.HS = (int)h->HS; P.hostpass = 0;
+    }
     *out = h;
     return TTX_OK;
 }
@@ -392,6 +524,9 @@ extern "C" void ttx_destroy(ttx_engine *h)
     if (h->h_msg) (void)hipHostFree(h->h_msg);
     if (h->h_tmp) (void)hipHostFree(h->h_tmp);
     if (h->h_abort) (void)hipHostFree(h->h_abort);
+    if (h->P.hidx) (void)hipHostFree(h->P.hidx);
+    if (h->P.hval) (void)hipHostFree(h->P.hval);
+    if (h->P.hreq) (void)hipHostFree(h->P.hreq);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -425,6 +560,15 @@ extern "C" int ttx_set_transport(ttx_engine *h, const ttx_transport *t)
     h->cb = *t; h->have_cb = true;
     return TTX_OK;
 }
+
+extern "C" int ttx_set_integrand_host(ttx_engine *h, ttx_host_fun fun, const double *par)
+{
+    if (!h || !fun) return fail(TTX_EINVAL, "ttx_set_integrand_host: null argument");
+    if (h->cfg.fun_id != TTX_FUN_HOST) return fail(TTX_ESTATE, "ttx_set_integrand_host: the engine was not created with fun_id = TTX_FUN_HOST");
+    h->hfun = fun; h->hfun_par = par;
+    return TTX_OK;
+}
+extern "C" int64_t ttx_host_calls(const ttx_engine *h) { return h ? h->host_calls : 0; }
 
 // messages of the boundary groups to the neighbouring GPUs (device buffers; after k_exch_pack)
 static int xfer_neighbours(ttx_engine *h)
@@ -502,7 +646,7 @@ static double erank_host(const ttx_engine *h, const int32_t *r)
     return (std::sqrt(b * b + 4.0 * a * s) - b) / (2.0 * a);
 }
 
-// Fortran Ew.d for non-negative values
+// Fortran Ew.d (the optional leading zero is dropped when the sign needs its place)
 static std::string fmt_e(int w, int dgt, double v)
 {
     char tmp[64], body[64];
@@ -516,7 +660,9 @@ static std::string fmt_e(int w, int dgt, double v)
         snprintf(body, sizeof body, ".%sE%c%02d", digs.c_str(), ex < 0 ? '-' : '+', abs(ex));
     } else snprintf(body, sizeof body, ".%sE+00", std::string(dgt, '0').c_str());
     std::string s = body;
-    if ((int)s.size() + 1 <= w) s = "0" + s;
+    const bool neg = std::signbit(v) && v != 0.0;
+    if ((int)s.size() + 1 + (neg ? 1 : 0) <= w) s = "0" + s;
+    if (neg) s = "-" + s;
     if ((int)s.size() < w) s = std::string(w - s.size(), ' ') + s;
     return s;
 }
@@ -628,6 +774,15 @@ static int run_impl(ttx_engine *h)
         if (h->cluster && (rc = ensure_lds(reinterpret_cast<const void *>(k_sweep_cluster), h->lds_cluster, a_cluster))) return rc;
     }
     if (h->cluster) *h->h_abort = 0;
+    // an evaluating kernel: once with the device integrand; with a host integrand twice around the host's calls
+    auto EV = [&](auto &&launch) -> int {
+        if (FUN != FUN_HOST) { launch(P); return TTX_OK; }
+        DevProb Q = P;
+        Q.hostpass = 1; launch(Q);
+        if (int rc_ = host_eval(h)) return rc_;
+        Q.hostpass = 2; launch(Q);
+        return TTX_OK;
+    };
     // ---- reset state (lib/dmrgg.f90:96-100, 141-148, 279-288) ----
     hipLaunchKernelGGL(k_reset, dim3(64), dim3(256), 0, st, P, h->SB, h->QB);
     // ---- initial cross (:151-301) ----
@@ -640,8 +795,8 @@ static int run_impl(ttx_engine *h)
         const int srows = lds_s <= 150 * 1024 ? 1 : 0;
         static size_t a_samp = 0;
         if (srows && (rc = ensure_lds(reinterpret_cast<const void *>(k_init_samples<FUN>), lds_s, a_samp))) return rc;
-        hipLaunchKernelGGL(k_init_samples<FUN>, dim3(G), dim3(256), srows ? lds_s : h->lds_par, st, P, snum, nn, srows, 0);
-        hipLaunchKernelGGL(k_init_fibers<FUN>, dim3(h->NC, G), dim3(256), h->lds_par, st, P);
+        if ((rc = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_init_samples<FUN>, dim3(G), dim3(256), srows ? lds_s : h->lds_par, st, Q, snum, nn, FUN == FUN_HOST ? 0 : srows, 0); }))) return rc;
+        if ((rc = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_init_fibers<FUN>, dim3(h->NC, G), dim3(256), h->lds_par, st, Q); }))) return rc;
         hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), 0, st, P);
         hipLaunchKernelGGL(k_init_final, dim3(G), dim3(256), 0, st, P);
     }
@@ -708,10 +863,10 @@ static int run_impl(ttx_engine *h)
                 hipLaunchKernelGGL(k_de_tables, dim3((2 * (d + 1) * h->RM + 255) / 256, G), dim3(256), 0, st, P, dir, pp);
             }
             if (h->cfg.pivoting >= 0) {
-                { KScope ks(h, TTX_K_LOTTERY); hipLaunchKernelGGL(k_lottery<FUN>, dim3(G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals); }
+                { KScope ks(h, TTX_K_LOTTERY); if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_lottery<FUN>, dim3(P.lot_nb, G), dim3(P.lot_nb == 1 ? 512 : 256), h->lds_lot, st, Q, dir, pp, h->lot_vals); })) return rc_; }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
                 for (int hh = 0; hh < h->H; hh++)
-                    hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode, h->half_vals);
+                    if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, Q, hh, dir, h->mode, h->half_vals); })) return rc_;
             } else {
                 // full pivoting (:341-408): every superblock column through the half-step kernel, global arg-max,
                 // then the cross through the winner (evaluation only)
@@ -737,7 +892,7 @@ static int run_impl(ttx_engine *h)
             }
             hipLaunchKernelGGL(k_exch_max_apply, dim3(G), dim3(256), 0, st, P, h->W > 1 ? 1 : 0, nproc > 1 ? 1 : 0);
             if (nproc > 1)
-                hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + 16 + sizeof(short) * 2 * (((d + 7) & ~7) + 8) + sizeof(double) * (64 * 64 + 4), st, P);
+                if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + 16 + sizeof(short) * 2 * (((d + 7) & ~7) + 8) + sizeof(double) * (64 * 64 + 4), st, Q); })) return rc_;
         }
         if (pipe) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
         if (pipe) HIPCHECK(hipEventRecord(h->ev_sum[slot], st));     // k_sweep_end wrote the summary into the pinned slot
@@ -870,6 +1025,10 @@ extern "C" int ttx_run(ttx_engine *h)
     switch (h->cfg.fun_id) {
         case TTX_FUN_ISING: return run_impl<FUN_ISING>(h);
         case TTX_FUN_STDNORM: return run_impl<FUN_STDNORM>(h);
+        case TTX_FUN_HOST:
+            if (!h->hfun) return fail(TTX_ESTATE, "ttx_run: call ttx_set_integrand_host first");
+            h->host_calls = 0;
+            return run_impl<FUN_HOST>(h);
         default: return run_impl<FUN_MVN>(h);
     }
 }
@@ -1071,7 +1230,20 @@ static int accchk_impl(ttx_engine *h, int nlot, double *einf, double *efro, doub
     HIPCHECK(hipMalloc((void **)&dout, sizeof(double) * 4 * (size_t)nlot));
     HIPCHECK(hipMemcpy(downer, owner.data(), sizeof(int) * (d + 2), hipMemcpyHostToDevice));
     size_t lds = sizeof(double) * (h->par.size() + 2 * h->RM + 4) + sizeof(int) * (d + 4);
-    hipLaunchKernelGGL(k_accchk<FUN>, dim3(nlot), dim3(64), lds, h->stream, P, (unsigned long long)g0s.rngpos, nlot, (const int *)downer, dout, dind);
+    if (FUN == FUN_HOST) {
+        // chunks of at most G*HS samples: index pass, the user's function on the host, value pass
+        const int chunk = (int)std::min<size_t>((size_t)h->G * h->HS, 65535);
+        for (int il0 = 0; il0 < nlot; il0 += chunk) {
+            const int cnt = std::min(chunk, nlot - il0);
+            DevProb Q = P;
+            Q.hostpass = 1;
+            hipLaunchKernelGGL(k_accchk<FUN>, dim3(cnt), dim3(64), lds, h->stream, Q, (unsigned long long)g0s.rngpos, nlot, (const int *)downer, dout, dind, il0);
+            if (int rc_ = host_eval(h)) return rc_;
+            Q.hostpass = 2;
+            hipLaunchKernelGGL(k_accchk<FUN>, dim3(cnt), dim3(64), lds, h->stream, Q, (unsigned long long)g0s.rngpos, nlot, (const int *)downer, dout, dind, il0);
+        }
+    } else
+    hipLaunchKernelGGL(k_accchk<FUN>, dim3(nlot), dim3(64), lds, h->stream, P, (unsigned long long)g0s.rngpos, nlot, (const int *)downer, dout, dind, 0);
     std::vector<double> o(4 * (size_t)nlot);
     std::vector<int> ind((size_t)nlot * d);
     HIPCHECK(hipMemcpyAsync(o.data(), dout, sizeof(double) * o.size(), hipMemcpyDeviceToHost, h->stream));
@@ -1102,6 +1274,9 @@ extern "C" int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efr
     switch (h->cfg.fun_id) {
         case TTX_FUN_ISING: return accchk_impl<FUN_ISING>(h, nlot, einf, efro, ainf, afro, pivot);
         case TTX_FUN_STDNORM: return accchk_impl<FUN_STDNORM>(h, nlot, einf, efro, ainf, afro, pivot);
+        case TTX_FUN_HOST:
+            if (!h->hfun) return fail(TTX_ESTATE, "dtt_accchk: call ttx_set_integrand_host first");
+            return accchk_impl<FUN_HOST>(h, nlot, einf, efro, ainf, afro, pivot);
         default: return accchk_impl<FUN_MVN>(h, nlot, einf, efro, ainf, afro, pivot);
     }
 }
@@ -1311,7 +1486,10 @@ extern "C" int ttx_dot(ttx_engine *x, ttx_engine *y, double *val)
     HIPCHECK(hipStreamSynchronize(y->stream));
     for (int i = 1; i <= d; i++) {
         const int rx0 = x->rfinal[i - 1], rx1 = x->rfinal[i], ry0 = y->rfinal[i - 1], ry1 = y->rfinal[i], n = x->n1[i];
-        if ((size_t)rx1 * ry1 > (size_t)x->RM * x->RM || (size_t)rx0 * n * ry1 > x->P.CS) return fail(TTX_EINVAL, "dtt_dot: ranks of y exceed the work space of x");
+        // x's scratch holds: core i of y packed (ry0*n*ry1 -> Wb), phi*core (rx0*n*ry1 -> Wc), the r x r interface matrices (Sm)
+        if ((size_t)rx1 * ry1 > (size_t)x->RM * x->RM || (size_t)rx0 * ry0 > (size_t)x->RM * x->RM || (size_t)rx0 * n * ry1 > x->P.CS ||
+            (size_t)ry0 * n * ry1 > x->P.CS)
+            return fail(TTX_EINVAL, "dtt_dot: ranks of y exceed the work space of x (call dot_product(y, x) or raise maxrank of x)");
         hipLaunchKernelGGL(k_pack_core, g1((size_t)ry0 * n * ry1), dim3(256), 0, x->stream, core_dev(y, i), x->Wb, ry0, n, ry1, y->RM, y->P.SS, 0);
         gemm(x, rx0, n * ry1, ry0, phi, rx0, x->Wb, ry0, x->Wc, rx0);                       // :1169
         hipLaunchKernelGGL(k_pack_core, g1((size_t)rx0 * n * rx1), dim3(256), 0, x->stream, core_dev(x, i), x->Wa, rx0, n, rx1, x->RM, x->P.SS, 0);
@@ -1336,20 +1514,27 @@ extern "C" int ttx_zquad(ttx_engine *h, int32_t nf, const double *w, double *out
     std::vector<const double *> cp(d + 2, nullptr);
     for (int k = 1; k <= d; k++) cp[k] = core_dev(h, k);
     std::vector<int> rr(h->rfinal.begin(), h->rfinal.end());
+    // the chain kernel keeps two complex r x r matrices of the LARGEST OCCURRING rank in LDS
+    int rmax = 1;
+    for (int k = 0; k <= d; k++) rmax = std::max(rmax, rr[k]);
+    const size_t lds = sizeof(double) * 4 * (size_t)RM * RM;
+    if (lds > 160 * 1024) return fail(TTX_EINVAL, "ztt_quad: maxrank %d needs %zu bytes of LDS for the chain (limit 160 KB, maxrank <= 71)", RM, lds);
+    // the five temporaries are released on every path out of this function
+    struct Tmp { std::vector<void *> p; ~Tmp() { for (void *q : p) (void)hipFree(q); } } tmp;
+    auto dalloc = [&](void **q, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(q, bytes); if (e == hipSuccess) tmp.p.push_back(*q); return e; };
     double *dw, *dtq, *dout; const double **dcp; int *dr;
-    HIPCHECK(hipMalloc((void **)&dw, sizeof(double) * 2 * sumn * nf)); HIPCHECK(hipMalloc((void **)&dtq, sizeof(double) * (size_t)nf * (d + 1) * 2 * RM * RM));
-    HIPCHECK(hipMalloc((void **)&dout, sizeof(double) * 2 * nf)); HIPCHECK(hipMalloc((void **)&dcp, sizeof(double *) * (d + 2))); HIPCHECK(hipMalloc((void **)&dr, sizeof(int) * (d + 1)));
+    HIPCHECK(dalloc((void **)&dw, sizeof(double) * 2 * sumn * nf)); HIPCHECK(dalloc((void **)&dtq, sizeof(double) * (size_t)nf * (d + 1) * 2 * RM * RM));
+    HIPCHECK(dalloc((void **)&dout, sizeof(double) * 2 * nf)); HIPCHECK(dalloc((void **)&dcp, sizeof(double *) * (d + 2))); HIPCHECK(dalloc((void **)&dr, sizeof(int) * (d + 1)));
     HIPCHECK(hipMemcpy(dw, w, sizeof(double) * 2 * sumn * nf, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dcp, cp.data(), sizeof(double *) * (d + 2), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dr, rr.data(), sizeof(int) * (d + 1), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_zquad_build, dim3(d, nf), dim3(256), 0, h->stream, d, RM, h->NM, h->P.SS, h->P.n, (const int *)dr, (const double *const *)dcp, (const double *)dw, 2 * sumn, dtq);
-    const size_t lds = sizeof(double) * 4 * (size_t)RM * RM;
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_zquad_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t a_zq = 0;
+    if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_zquad_chain), lds, a_zq)) return rc_;
     hipLaunchKernelGGL(k_zquad_chain, dim3(nf), dim3(256), lds, h->stream, d, RM, (const int *)dr, (const double *)dtq, dout);
     HIPCHECK(hipMemcpyAsync(out, dout, sizeof(double) * 2 * nf, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     HIPCHECK(hipGetLastError());
-    (void)hipFree(dw); (void)hipFree(dtq); (void)hipFree(dout); (void)hipFree(dcp); (void)hipFree(dr);
     return TTX_OK;
 }
 
@@ -1469,6 +1654,33 @@ extern "C" int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemcpy(out, dout, sizeof(double) * npts, hipMemcpyDeviceToHost));
     (void)hipFree(dn); (void)hipFree(dpar); (void)hipFree(dind); (void)hipFree(dout); if (daux) (void)hipFree(daux);
+    return TTX_OK;
+}
+
+__global__ void k_exp_list(long long n, const double *x, double *out)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = ttx_exp(x[t]);
+}
+extern "C" int ttx_k_exp(int32_t device, int64_t n, const double *x, double *out)
+{
+    if (!x || !out || n < 1) return fail(TTX_EINVAL, "ttx_k_exp: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "no HIP device");
+    HIPCHECK(hipSetDevice(device));
+    double *dx, *dy;
+    HIPCHECK(hipMalloc((void **)&dx, sizeof(double) * n)); HIPCHECK(hipMalloc((void **)&dy, sizeof(double) * n));
+    HIPCHECK(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_exp_list, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (long long)n, dx, dy);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(out, dy, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy);
+    return TTX_OK;
+}
+extern "C" int ttx_exp_host(int64_t n, const double *x, double *out)
+{
+    if (!x || !out || n < 0) return fail(TTX_EINVAL, "ttx_exp_host: bad argument");
+    for (int64_t i = 0; i < n; i++) out[i] = ttx_exp(x[i]);
     return TTX_OK;
 }
 

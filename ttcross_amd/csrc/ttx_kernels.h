@@ -7,6 +7,7 @@
 #include <math.h>
 #include "ttx_cdf.h"
 #include "ttx_dev.h"
+#include "ttx_exp.h"
 
 #ifdef TTX_STAMPS
 #define STAMP_DECL const bool t_me = (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0); long long t_prev = wall_clock64(); int t_slot = 0
@@ -20,6 +21,7 @@
 #define FUN_ISING 1
 #define FUN_STDNORM 2
 #define FUN_MVN 3
+#define FUN_HOST 4     // values come from the host (the user callback of lib/dmrgg.f90:18), see DevProb::hostpass
 
 // ------------------------------------------------------------------------------------------------
 // address helpers
@@ -75,7 +77,7 @@ __device__ __forceinline__ double f_stdnorm(int m, const double *par, IDX idx)
     // test_crs_stdnorm.f90:154-170
     double s = 0.0;
     for (int i = 1; i <= m; i++) { double x = par[idx(i) - 1]; s = s + x * x; }
-    return exp(-s);
+    return ttx_exp(-s);
 }
 
 template <class IDX>
@@ -91,7 +93,7 @@ __device__ __forceinline__ double f_mvn(int m, const double *par, const double *
             ex = ex + di * ic[(i - 1) + (size_t)m * (j - 1)] * dj;
         }
     }
-    return exp(-0.5 * ex) / norm;
+    return ttx_exp(-0.5 * ex) / norm;
 }
 
 // The same quadratic form from rows of DIFFERENCES x - mu staged in LDS: dims 1..A from da, dim A+1 = d1, (NS == 2:
@@ -121,12 +123,27 @@ __device__ __forceinline__ double f_mvn_rows(int m, const double *icT, double no
         mvn_dims<NS>(da, A, d1, d2, db, nb, [&](double dj) { ex = ex + di * row[j] * dj; j++; });
         i++;
     });
-    return exp(-0.5 * ex) / norm;
+    return ttx_exp(-0.5 * ex) / norm;
 }
 
-template <int FUN, class IDX>
-__device__ __forceinline__ double eval_fun(const DevProb &P, const double *par, IDX idx)
+// host integrand: pass 1 records the multi-index of the point in slot `slot`, pass 2 returns the host's value
+template <class IDX>
+__device__ __forceinline__ double f_host(const DevProb &P, IDX idx, long slot)
 {
+    if (P.hostpass == 1) {
+        short *row = P.hidx + (size_t)slot * P.d;
+        for (int s = 1; s <= P.d; s++) row[s - 1] = (short)idx(s);
+        P.hreq[slot] = 1;
+        return 0.0;
+    }
+    return P.hval[slot];
+}
+#define HOST_PASS1(FUN, P) ((FUN) == FUN_HOST && (P).hostpass == 1)
+
+template <int FUN, class IDX>
+__device__ __forceinline__ double eval_fun(const DevProb &P, const double *par, IDX idx, long slot = -1)
+{
+    if (FUN == FUN_HOST) return f_host(P, idx, slot);
     if (FUN == FUN_ISING) return f_ising(P.ising_id, P.d, P.n[1], par, idx);
     if (FUN == FUN_STDNORM) return f_stdnorm(P.d, par, idx);
     return f_mvn(P.d, par, P.aux, P.mvn_norm, idx);
@@ -350,11 +367,11 @@ __device__ __forceinline__ double f_ising_c4(int m, int n1, const double *par, c
     return f;
 }
 template <int FUN>
-__device__ __forceinline__ double eval_src4(const DevProb &P, const double *par, const Src4 &S)
+__device__ __forceinline__ double eval_src4(const DevProb &P, const double *par, const Src4 &S, long slot = -1)
 {
     if (FUN == FUN_ISING && P.ising_id == 1) return f_ising_c4(P.d, P.n[1], par, S);
     if (FUN == FUN_ISING) return f_ising_de<2>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.s1, S.s2, S.pb);
-    return eval_fun<FUN>(P, par, S);
+    return eval_fun<FUN>(P, par, S, slot);
 }
 
 // Same recurrences over rows of VALUES (node / weight doubles staged in LDS, 16-byte aligned, padded): a step
@@ -415,11 +432,11 @@ __device__ __forceinline__ double f_ising_c3v(int m, int A, const double *an, co
 
 // aligned = rows are 16-byte aligned and padded (half-step / lottery staging); else the generic accessor
 template <int FUN, bool ALIGNED>
-__device__ __forceinline__ double eval_src3(const DevProb &P, const double *par, const Src3 &S)
+__device__ __forceinline__ double eval_src3(const DevProb &P, const double *par, const Src3 &S, long slot = -1)
 {
     if (ALIGNED && FUN == FUN_ISING && P.ising_id == 1) return f_ising_c3(P.d, P.n[1], par, S);
     if (ALIGNED && FUN == FUN_ISING) return f_ising_de<1>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.self, 0, S.pb);
-    return eval_fun<FUN>(P, par, S);
+    return eval_fun<FUN>(P, par, S, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -554,7 +571,7 @@ __global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int n
     if (!ldsrows)                                             // rows do not fit the LDS: generic accessor
         for (int il = tid; il < nn * snum; il += blockDim.x) {
             DiagIdx ix{P.n, il % nn + 1, il / nn};
-            double f = eval_fun<FUN>(P, par, ix);
+            double f = eval_fun<FUN>(P, par, ix, (long)g * P.HS + il);
             double a = fabs(f);
             if (a > ba || (a == ba && il < bi)) { ba = a; bv = f; bi = il; }
         }
@@ -567,10 +584,11 @@ __global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int n
         const int self = row[m - 1];
         row[m - 1] = 1;                                       // pad of the dims 1..m-1 part
         Src3 sx{row, m - 1, self, row + m};                   // empty right part: nb = 0, never read
-        double f = eval_src3<FUN, true>(P, par, sx);
+        double f = eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + il);
         double a = fabs(f);
         if (a > ba || (a == ba && il < bi)) { ba = a; bv = f; bi = il; }
     }
+    if (HOST_PASS1(FUN, P)) return;
     block_argmax(ba, bv, bi, sha, shv, shi);
     if (tid == 0) {
         gs.amax = ba;                                             // :180,201
@@ -604,10 +622,11 @@ __global__ __launch_bounds__(256) void k_init_fibers(DevProb P)
     double mx = 0.0;
     for (int j = tid; j < P.n[p]; j += blockDim.x) {
         FixIdx ix{P.ind0, p, j + 1};
-        double f = eval_fun<FUN>(P, par, ix);
+        double f = eval_fun<FUN>(P, par, ix, (long)g * P.HS + (long)blockIdx.x * P.NM + j);
         A[(size_t)P.RM * j] = f;
         mx = fmax(mx, fabs(f));
     }
+    if (HOST_PASS1(FUN, P)) return;
     mx = block_max(mx, shm);
     if (tid == 0) { atomic_max_pos(&gs.amax, mx); atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)P.n[p]); }
 }
@@ -691,6 +710,7 @@ __global__ __launch_bounds__(256) void k_reset(DevProb P, size_t SB, size_t QB)
     for (size_t x = t0; x < SB; x += nt) P.sumsend[x] = 0.0;
     for (size_t x = t0; x < QB; x += nt) P.qsend[x] = 0.0;
     if (t0 < 4) P.ctl[t0] = 0;
+    if (P.lot_ctr) for (size_t x = t0; x < (size_t)P.G; x += nt) P.lot_ctr[x] = 0u;
     if (P.cl_ctr) {
         for (size_t x = t0; x < (size_t)P.G; x += nt) P.cl_ctr[x] = 0u;
         ClPart z; z.ab = 0.0; z.bb = 0.0; z.mx = 0.0; z.ix = 0; z.pad = 0;
@@ -817,7 +837,9 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     __shared__ int nzc, nzr, nsc, nsr;
     __shared__ ttx_cdfseg segc[TTX_MAXSEG], segr[TTX_MAXSEG];
     __shared__ double sha[8], shv[8]; __shared__ int shi[8];
-    const int g = blockIdx.x, tid = threadIdx.x, m = P.d;
+    __shared__ int s_last;
+    const int g = blockIdx.y, tid = threadIdx.x, m = P.d;
+    const int nbl = (int)gridDim.x, blk = (int)blockIdx.x;
     GroupState &gs = P.gs[g];
     STAMP_DECL;
     if (tid == 0) bond_state(P, g, dir, pp, st);
@@ -854,7 +876,9 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     __shared__ unsigned long long sA[2];
     if (tid == 32) sA[0] = ttx_minstd_pow(2 * gs.rngpos + 1);
     if (tid == 33) sA[1] = ttx_minstd_pow(2 * (gs.rngpos + nlot) + 1);
-    unsigned long long bil = ttx_minstd_pow(2ull * tid);
+    const int CH = (nbl == 1) ? nlot : 64;                     // candidates per block
+    const int il_first = blk * CH + tid, il_end = min(nlot, (blk + 1) * CH);
+    unsigned long long bil = ttx_minstd_pow(2ull * (unsigned long long)il_first);
     // zero-weight positions (existing pivots), :432-439
     const int *vp = vip_ptr(P, g, p, first);
     if (tid < r1) {
@@ -895,9 +919,9 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     STAMP(gs, 0);   // 2: cdf
     double ma = 0.0;
     double ba = -1.0, bv = 0.0; int bi = INT_MAX;
-    for (int il = tid; il < nlot; il += blockDim.x) {
+    for (int il = il_first; il < il_end; il += blockDim.x) {
         double d1, d2;
-        if (il < (int)blockDim.x) { d1 = ttx_flang_from_word(ttx_mulmod31(sA[0], bil)); d2 = ttx_flang_from_word(ttx_mulmod31(sA[1], bil)); }
+        if (il == il_first) { d1 = ttx_flang_from_word(ttx_mulmod31(sA[0], bil)); d2 = ttx_flang_from_word(ttx_mulmod31(sA[1], bil)); }
         else { d1 = ttx_flang_draw(gs.rngpos + il); d2 = ttx_flang_draw(gs.rngpos + nlot + il); }
         const int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);      // rnd.f90:122-123
         const int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
@@ -914,7 +938,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
             f = de_finish<2>(P.ising_id, ap, m, P.n[1], par, pa_, p - 1, j, k, pb_);
         } else {
             Src4 sx{LT + (size_t)(i - 1) * VS, p - 1, j, k, RT + (size_t)(q - 1) * VS};
-            f = eval_src4<FUN>(P, par, sx);                                        // :455-463
+            f = eval_src4<FUN>(P, par, sx, (long)g * P.HS + il);                   // :455-463
         }
         ma = fmax(ma, fabs(f));
         const double *c = Cp + (i - 1) + (size_t)P.RM * (j - 1), *w = Wq + (k - 1) + (size_t)P.NM * (q - 1);
@@ -926,8 +950,41 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         if (a > ba || (a == ba && il < bi)) { ba = a; bv = b; bi = il; }
     }
     STAMP(gs, 0);   // 3: selection + eval + ddot
+    if (HOST_PASS1(FUN, P)) return;
     ma = block_max(ma, sha);
     block_argmax(ba, bv, bi, sha, shv, shi);
+    if (nbl > 1) {
+        // this block's partial, then the arrival counter; the last block folds all partials (blocks sit on different XCDs:
+        // the fence pair makes the records visible across their L2s)
+        LotPart *lp = P.lotp + (size_t)g * P.lot_nb;
+        if (tid == 0) {
+            LotPart r; r.ab = ba; r.bv = bv; r.ma = ma; r.il = bi; r.pad = 0;
+            if (bi != INT_MAX) { r.i = lot[4 * bi]; r.j = lot[4 * bi + 1]; r.k = lot[4 * bi + 2]; r.q = lot[4 * bi + 3]; } else { r.i = r.j = r.k = r.q = 0; }
+            lp[blk] = r;
+            __threadfence();
+            s_last = (atomicAdd(&P.lot_ctr[g], 1u) == (unsigned)(nbl - 1));
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) {
+            __threadfence();
+            P.lot_ctr[g] = 0u;
+            int wi = 0, wj = 0, wk = 0, wq = 0;
+            ba = -1.0; bv = 0.0; bi = INT_MAX; ma = 0.0;
+            for (int b = 0; b < nbl; b++) {
+                const LotPart r = lp[b];
+                ma = fmax(ma, r.ma);
+                if (r.ab > ba || (r.ab == ba && r.il < bi)) { ba = r.ab; bv = r.bv; bi = r.il; wi = r.i; wj = r.j; wk = r.k; wq = r.q; }
+            }
+            gs.amax = fmax(gs.amax, ma);                         // :467
+            gs.neval += nlot;                                    // :465
+            gs.rngpos += 2ull * nlot;
+            st.ii = wi; st.jj = wj; st.kk = wk; st.qq = wq;      // :479-484
+            st.pivot = bv;
+            gs.S[0] = st;
+        }
+        return;
+    }
     if (tid == 0) {
         gs.amax = fmax(gs.amax, ma);                             // :467
         gs.neval += nlot;                                        // :465
@@ -1055,11 +1112,12 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             Src3 sx;
             if (iscol) { sx.pa = vt + (size_t)u * VS; sx.A = p - 1; sx.self = v + 1; sx.pb = fxs; }
             else       { sx.pa = fxs; sx.A = p; sx.self = u + 1; sx.pb = vt + (size_t)v * VS; }
-            a = eval_src3<FUN, true>(P, par, sx);                             // :520-526 / :553-559
+            a = eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + t);         // :520-526 / :553-559
         }
         if (mode != 3) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
     }
     STAMP(gs, 1);   // 2: eval
+    if (HOST_PASS1(FUN, P)) return;
     double mx = block_max(live ? fabs(a) : 0.0, sha);
     if (tid == 0 && mode != 1) atomic_max_pos(&gs.amax, mx);                  // :531 / :564 (the piv = 0 branch :492-513 does not touch amax)
     const int crs = cur.crs + 1;
@@ -1607,11 +1665,14 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
             __syncthreads();
             if (tid == rrp) {
                 Src3 sx{rowA, p - 1, (int)vp[1], rowB};
-                a = eval_src3<FUN, true>(P, par, sx);
-                atomic_max_pos(&gs.amax, fabs(a));
-                if (k == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n2);   // :936
+                a = eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + k);
+                if (!HOST_PASS1(FUN, P)) {
+                    atomic_max_pos(&gs.amax, fabs(a));
+                    if (k == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n2);   // :936
+                }
             }
         }
+        if (HOST_PASS1(FUN, P)) return;
         if (tid < rp) A[tid + (size_t)P.RM * k + P.SS * snew] = a;
         // row(p+1)(:, k, new) = L(p)^-1 * column : d2_luar(n(p+1), r(p), inv(p), .) :940-951
         const double *gI = inv_ptr(P, g, p, first);
@@ -1652,11 +1713,14 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
             __syncthreads();
             if (tid == rrp) {
                 Src3 sx{rowA, p - 1, j + 1, rowB};
-                y = eval_src3<FUN, true>(P, par, sx);
-                atomic_max_pos(&gs.amax, fabs(y));
-                if (j == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n1);
+                y = eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + P.NM + j);
+                if (!HOST_PASS1(FUN, P)) {
+                    atomic_max_pos(&gs.amax, fabs(y));
+                    if (j == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n1);
+                }
             }
         }
+        if (HOST_PASS1(FUN, P)) return;
         if (tid < rp) A[inew + (size_t)P.RM * j + P.SS * tid] = y;
         // col(p)(new, j, :) = row * U(p)^-1 : d2_lual(n(p), r(p), inv(p), .) dmrggmp.f90:622
         const double *gI = inv_ptr(P, g, p, first);
@@ -1814,10 +1878,10 @@ __global__ __launch_bounds__(TTX_BLK) void k_resid_argmax_stream(long long m, in
 // aval, aval^2); ind_out[il*d..] = the sample's multi-index
 // ------------------------------------------------------------------------------------------------
 template <int FUN>
-__global__ __launch_bounds__(64) void k_accchk(DevProb P, unsigned long long rngpos, int nlot, const int *owner, double *out, int *ind_out)
+__global__ __launch_bounds__(64) void k_accchk(DevProb P, unsigned long long rngpos, int nlot, const int *owner, double *out, int *ind_out, int il0)
 {
     extern __shared__ __align__(16) double dyn[];
-    const int il = blockIdx.x, tid = threadIdx.x, m = P.d;
+    const int il = il0 + blockIdx.x, tid = threadIdx.x, m = P.d;
     double *par = dyn, *x = dyn + ((P.npar + 1) & ~1), *z = x + P.RM;
     int *ind = (int *)(z + P.RM);
     for (int s = tid; s < P.npar; s += 64) par[s] = P.par[s];
@@ -1828,7 +1892,8 @@ __global__ __launch_bounds__(64) void k_accchk(DevProb P, unsigned long long rng
     }
     __syncthreads();
     double aval = 0.0;
-    if (tid == 0) { ListIdx ix{ind}; aval = eval_fun<FUN>(P, par, ix); }
+    if (tid == 0) { ListIdx ix{ind}; aval = eval_fun<FUN>(P, par, ix, (long)blockIdx.x); }
+    if (HOST_PASS1(FUN, P)) return;
     // dtt_ijk (lib/tt.f90:630-652): x = U_m(:, ind_m, 1); for i = m-1..1: x = U_i(:, ind_i, :) x
     {
         const int g = owner[m], first = P.gs[g].first;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_norm_log(size_t n, double *x, double *
 // final rescaling of every core by exp(acc[0]/d) (times acc[1] for the core whose norm was only measured)
 __global__ void k_scal_core_acc(double *core, int r0, int n, int r1, int RM, size_t SS, const double *acc, int d, int extra)
 {
-    const double a = exp(acc[0] / d) * (extra ? acc[1] : 1.0);
+    const double a = ttx_exp(acc[0] / d) * (extra ? acc[1] : 1.0);
     const size_t tot = (size_t)r0 * n * r1;
     for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < tot; x += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(x % r0); size_t c = x / r0; int j = (int)(c % n), s = (int)(c / n);

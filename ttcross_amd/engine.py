@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_uint8, c_uin
 
 import numpy as np
 
-TTX_FUN_ISING, TTX_FUN_STDNORM, TTX_FUN_MVN = 1, 2, 3
+TTX_FUN_ISING, TTX_FUN_STDNORM, TTX_FUN_MVN, TTX_FUN_HOST = 1, 2, 3, 4
 K_NAMES = ("lottery", "halfstep", "accept", "exchange", "quad", "other")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -101,6 +101,11 @@ def load_library():
                              POINTER(c_double), c_int32, c_int64, POINTER(c_int32), POINTER(c_double)]
     L.ttx_k_lottery.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),
                                 c_uint64, POINTER(c_int32)]
+    L.ttx_set_integrand_host.argtypes = [c_void_p, c_void_p, POINTER(c_double)]
+    L.ttx_host_calls.argtypes = [c_void_p]
+    L.ttx_host_calls.restype = c_int64
+    L.ttx_k_exp.argtypes = [c_int32, c_int64, POINTER(c_double), POINTER(c_double)]
+    L.ttx_exp_host.argtypes = [c_int64, POINTER(c_double), POINTER(c_double)]
     _lib = L
     return L
 
@@ -267,6 +272,18 @@ class TTCross:
         tr = _Transport(None, self._cb[0], self._cb[1])
         _check(load_library().ttx_set_transport(self._h, ctypes.byref(tr)))
 
+    def set_integrand_host(self, fun_addr, par=None):
+        """The reference's user callback `fun(m, ind, n, par)` (lib/dmrgg.f90:18) for an engine created with
+        fun_id = TTX_FUN_HOST: fun_addr is the address of a C / Fortran function with that interface (everything by
+        reference), par the array handed to it untouched.  Fibers are then evaluated on the host, the sweep on the GPU."""
+        self._hpar = None if par is None else np.ascontiguousarray(par, dtype=np.float64)
+        _check(load_library().ttx_set_integrand_host(self._h, c_void_p(fun_addr), _dp(self._hpar)))
+        return self
+
+    @property
+    def host_calls(self):
+        return int(load_library().ttx_host_calls(self._h))
+
     def sweep_path(self):
         """'chain', 'fused' or 'cluster': the sweep implementation chosen at creation (TTX_SWEEP)."""
         L = load_library()
@@ -421,3 +438,19 @@ def k_lottery(npnt, m, n, zcol, zrow, rngpos=0, device=0):
     pts = np.zeros(2 * npnt, dtype=np.int32)
     _check(load_library().ttx_k_lottery(device, npnt, m, n, zc.size, _ip(zc), _ip(zr), rngpos, _ip(pts)))
     return pts.reshape(2, npnt)
+
+
+def k_exp(x, device=0):
+    """The integrands' exp (ttx_exp.h) evaluated on the device."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    _check(load_library().ttx_k_exp(device, x.size, _dp(x), _dp(out)))
+    return out
+
+
+def exp_host(x):
+    """The same source instantiated on the host (needs no GPU): pins ttx_exp.h against the run-time libm."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    _check(load_library().ttx_exp_host(x.size, _dp(x), _dp(out)))
+    return out

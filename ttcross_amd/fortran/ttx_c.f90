@@ -3,7 +3,7 @@
 module ttx_c
  use iso_c_binding
  implicit none
- integer(c_int32_t),parameter :: TTX_FUN_ISING=1, TTX_FUN_STDNORM=2, TTX_FUN_MVN=3
+ integer(c_int32_t),parameter :: TTX_FUN_ISING=1, TTX_FUN_STDNORM=2, TTX_FUN_MVN=3, TTX_FUN_HOST=4
  type,bind(C) :: ttx_config
   integer(c_int32_t) :: d
   type(c_ptr) :: n
@@ -36,6 +36,18 @@ module ttx_c
   subroutine ttx_destroy(h) bind(C,name='ttx_destroy')
    import; type(c_ptr),value :: h
   end subroutine
+  function ttx_set_integrand_host(h,fun,par) bind(C,name='ttx_set_integrand_host') result(rc)   ! the user's `fun`, lib/dmrgg.f90:18
+   import; type(c_ptr),value :: h; type(c_funptr),value :: fun; type(c_ptr),value :: par; integer(c_int) :: rc
+  end function
+  function ttx_host_calls(h) bind(C,name='ttx_host_calls') result(n)
+   import; type(c_ptr),value :: h; integer(c_int64_t) :: n
+  end function
+  function ttx_comm_unique_id(id) bind(C,name='ttx_comm_unique_id') result(rc)   ! replaces mpi_init, test_crs_ising.f90:31-36
+   import; integer(c_int8_t) :: id(128); integer(c_int) :: rc
+  end function
+  function ttx_comm_init(h,id) bind(C,name='ttx_comm_init') result(rc)
+   import; type(c_ptr),value :: h; integer(c_int8_t) :: id(128); integer(c_int) :: rc
+  end function
   function ttx_run(h) bind(C,name='ttx_run') result(rc)
    import; type(c_ptr),value :: h; integer(c_int) :: rc
   end function
