@@ -172,6 +172,11 @@ int ttx_set_profile(ttx_engine *h, int on);
  * 0 multi-kernel chain (k_lottery / k_halfstep / k_accept per bond), 1 one workgroup per bond group for the whole
  * sweep (k_sweep_fused), 2 a cluster of workgroups per bond group for the whole sweep (k_sweep_cluster) */
 int ttx_sweep_path(const ttx_engine *h);
+/* runs of this engine that were replayed on the multi-kernel chain because a wait inside the cluster kernel timed out
+ * (its workgroups must all be resident at once; the launch is cooperative and gated by the occupancy calculator, so this
+ * is a safety net: after a fallback the engine stays on the chain path; results are identical on every path) */
+int ttx_cluster_fallbacks(const ttx_engine *h);
+int64_t ttx_resid_halfsteps(const ttx_engine *h);   /* rook half-steps of the last run that computed a residual + arg-max (all groups) */
 int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double ms[TTX_K_NKINDS], double bytes[TTX_K_NKINDS]);
 
 /* ---- kernel-level entry points used by the parity tests (host buffers in, host buffers out) ---- */
@@ -196,6 +201,11 @@ int ttx_k_lottery(int32_t device, int32_t npnt, int32_t m, int32_t n, int32_t nz
  * source on the host (needs no GPU) -- both exist so that tests can pin it against libm bit for bit. */
 int ttx_k_exp(int32_t device, int64_t n, const double *x, double *out);
 int ttx_exp_host(int64_t n, const double *x, double *out);
+
+/* latency probe (bench.py's latency model of the sweep kernels): ns per dependent fp64 multiply [0], per dependent
+ * multiply+add pair [1], per dependent L2 round trip (L1-bypassing pointer chase) [2], per dependent LDS read [3] and
+ * per fp64 IEEE division in a dependent chain [4], each measured on one wave */
+int ttx_k_latency_probe(int32_t device, double out[5]);
 
 /* placement probe: the XCD (XCC_ID hardware register) on which each of `nblocks` workgroups of a plain 1-D launch
  * ran; the cluster sweep kernel relies on workgroups being dealt round-robin to the 8 XCDs */

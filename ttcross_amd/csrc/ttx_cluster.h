@@ -16,7 +16,12 @@
 //     the current pivot, and -- for the whole launch -- the sorted pivot lists of every own bond;
 //   * every wait is bounded: a block that waits too long raises the abort flag (pinned host memory), all blocks leave,
 //     and the host reports the failure instead of hanging the GPU.
-// All blocks of all groups must be resident at once: the host only takes this path when G*NB <= number of CUs.
+// All blocks of all groups must be resident at once.  The host takes this path only when the grid fits HALF of what the
+// occupancy calculator says the device can hold for this kernel's LDS footprint (room for the forked quadrature and a
+// second engine); TTX_CLUSTER_COOP=1 additionally launches it as a COOPERATIVE kernel (the runtime itself then refuses a
+// grid that cannot be co-resident; ~30 us per launch dearer).  Should a wait still time out, the kernel stops every later
+// kernel of the sweep (ctl[0]) and ttx_run replays the run on the multi-kernel chain, which gives the identical result
+// (ttx_cluster_fallbacks).
 // Arithmetic and its order are identical to the other two paths (and to the oracle): same device functions, the
 // first-max rule is applied on global fiber positions, reused partial results are bit-identical by construction.
 #pragma once
@@ -112,6 +117,10 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
     const int bid = blockIdx.x;
     const int g = (bid & 7) + 8 * (bid / (8 * NB)), cb = (bid >> 3) % NB;     // cluster of group g lives on XCD g % 8
     if (g >= P.G || P.ctl[0]) return;
+    if (P.cl_test_abort && P.cl_test_abort == epoch && g == 0 && cb == 0) {    // test hook (TTX_CLUSTER_TEST_ABORT): a block that never arrives
+        if (threadIdx.x == 0) { __hip_atomic_store(P.cl_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); P.ctl[0] = 1; }
+        return;
+    }
     const int tid = threadIdx.x, m = P.d, RM = P.RM, NM = P.NM;
     const int lane = tid & 63, wv = tid >> 6;
     GroupState &gs = P.gs[g];
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 }
             }
             __syncthreads();
-            if (!s_ok) return;
+            if (!s_ok) { if (tid == 0) P.ctl[0] = 1; return; }      // aborted: the tail kernels of this sweep do nothing
             CST(9);
             mx = shm[0]; ab = sha[0]; bb = shv[0]; ix = shi[0];
             hcount++;
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         CST(14);
         // end of the bond step: appends and the new rank become visible to the whole cluster (every block read r[] of
         // this step before its first half-step barrier, so block 0 may already have overwritten r[p])
-        if (!cluster_sync(ctr, (++nbar) * (unsigned)NB, P.cl_abort, &s_ok)) return;
+        if (!cluster_sync(ctr, (++nbar) * (unsigned)NB, P.cl_abort, &s_ok)) { if (tid == 0) P.ctl[0] = 1; return; }
         CST(15);
         CST_END();
     }

@@ -1,0 +1,184 @@
+// ttx_de.h -- rook half-step for the Ising D / E integrands (test_crs_ising.f90:186-195): one WAVE per varying pivot.
+//
+// One evaluation of D/E is a chain of m(m+1)/2 pair factors multiplied in the reference's order -- 32 640 dependent
+// fp64 multiplies at BASELINE config 5 (D_256) -- so a half-step lasts as long as one wave needs for its chain, and
+// what counts is the number of instructions a wave issues per pair (fp64 VALU: one instruction per 4 cycles per wave).
+// k_halfstep gave every lane its own pivot: the tabulated factors came from per-lane global loads (8 in flight:
+// latency-bound, ~55 cycles per pair) and the node values of the bond-spanning pairs from per-lane LDS lookups.
+//
+// Here the 64 lanes of a wave are the MODE indices of one varying pivot (column half-step: left pivot pv, lanes = j;
+// row half-step: right pivot pv, lanes = k), so everything except the one free mode index is wave-uniform:
+//   * tabulated factors (TL of the left pivot, TR of the right pivot; k_de_tables lays a pivot's factors out in
+//     multiplication order) are STREAMED: the wave loads 64 consecutive factors with one coalesced 512-byte load,
+//     two batches ahead, parks them in a 64-entry LDS ring and multiplies them in as LDS broadcasts;
+//   * the node values of the left / right dims and the running products UL are staged once per wave as LDS arrays
+//     (broadcast reads, no index decoding);
+//   * the IEEE divisions of the bond-spanning pairs use the exact short sequence fdiv_unit when the host has verified
+//     that all nodes lie in [0,1] (P.de_unit), four instructions fewer than the general a/b;
+// The arithmetic per element -- every product, difference, quotient and their order -- is that of f_ising_de /
+// de_pairs_tab, hence of the oracle: results stay bit-identical.
+#pragma once
+#include "ttx_kernels.h"
+
+// wave-uniform stream of doubles g[0..total) consumed in order by all lanes of ONE wave
+struct WStream {
+    const double *g; double *buf; double rA, rB; int total, nextb, avail, rd;
+    __device__ __forceinline__ double ld(int b, int lane) const { const int ix = b * 64 + lane; return ix < total ? g[ix] : 1.0; }
+    __device__ __forceinline__ void init(const double *g_, int total_, double *buf_, int lane)
+    { g = g_; total = total_; buf = buf_; rA = ld(0, lane); rB = ld(1, lane); nextb = 2; avail = 0; rd = 0; }
+    __device__ __forceinline__ void refill(int lane)
+    {
+        __builtin_amdgcn_wave_barrier();
+        buf[lane] = rA; rA = rB; rB = ld(nextb, lane); nextb++; avail = 64; rd = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // a = (..((a * g[pos]) * g[pos+1]) ..) over the next cnt entries
+    __device__ __forceinline__ double chain(double a, int cnt, int lane)
+    {
+        while (cnt > 0) {
+            if (avail == 0) refill(lane);
+            const int mm = cnt < avail ? cnt : avail;
+            const double *p = buf + rd;
+            int k = 0;
+            for (; k + 8 <= mm; k += 8) {
+                double x[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) x[q] = p[k + q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) a = a * x[q];
+            }
+            for (; k < mm; k++) a = a * p[k];
+            rd += mm; avail -= mm; cnt -= mm;
+        }
+        return a;
+    }
+};
+
+// the bond-spanning tail of a row: pair with s2 (x2), then with the right dims xr[0..B) (LDS, wave-uniform)
+template <bool FAST>
+__device__ __forceinline__ void de_run(double &a, double u, double x2, const double *xr, int B)
+{
+    u = u * x2; a = a * de_t2<FAST>(u);
+    int j = 0;
+    for (; j + 4 <= B; j += 4) {                       // four independent divisions in flight; products in order
+        const double u1 = u * xr[j], u2 = u1 * xr[j + 1], u3 = u2 * xr[j + 2], u4 = u3 * xr[j + 3];
+        const double t1 = de_t2<FAST>(u1), t2 = de_t2<FAST>(u2), t3 = de_t2<FAST>(u3), t4 = de_t2<FAST>(u4);
+        a = a * t1; a = a * t2; a = a * t3; a = a * t4;
+        u = u4;
+    }
+    for (; j < B; j++) { u = u * xr[j]; a = a * de_t2<FAST>(u); }
+}
+
+// grid = (RM * ceil(NM/64) wave slots, groups), 64 threads.  Same contract as k_halfstep (modes 0, 1, 2).
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, int mode)
+{
+    extern __shared__ __align__(16) double dyn[];
+    __shared__ StepState cur;
+    const int g = blockIdx.y, lane = threadIdx.x, m = P.d;
+    GroupState &gs = P.gs[g];
+    if (lane == 0) { cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]); }
+    __syncthreads();
+    if (!cur.active || cur.done) { if (blockIdx.x == 0 && lane == 0) gs.S[h + 1] = cur; return; }
+    const bool iscol = (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
+    const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
+    const int nf = iscol ? r0 * n1 : n2 * r2;
+    const int nv = iscol ? r0 : r2, nm = iscol ? n1 : n2, nch = (nm + 63) >> 6;
+    const int npart = nv * nch;
+    const int w = blockIdx.x;
+    const int crs = cur.crs + 1;
+    const int havecol = cur.havecol | (iscol ? 1 : 0), haverow = cur.haverow | (iscol ? 0 : 1);
+    const int done = (mode == 1 || mode == 2) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
+    const bool resid = (mode == 0) && !done;
+    if (w == 0 && lane == 0) {
+        StepState nx = cur;
+        nx.crs = crs; nx.havecol = havecol; nx.haverow = haverow; nx.done = done;
+        nx.pending = resid ? (iscol ? 1 : 2) : 0;
+        nx.npart = npart;
+        gs.S[h + 1] = nx;
+        if (mode != 2) gs.neval += nf;                                        // :527 / :560 / :509
+        gs.bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
+        gs.n_resid += resid ? 1 : 0;
+    }
+    if (w >= npart) return;
+    const int pv = w / nch, vmode = (w - pv * nch) * 64 + lane;        // varying pivot, mode index (0-based)
+    const bool live = vmode < nm;
+    const int A = p - 1, B = m - p - 1;
+    const int pl = iscol ? pv : cur.ii - 1, qr = iscol ? cur.qq - 1 : pv;         // left / right pivot of this wave
+    const int n1m = P.n[1];
+    const double *nodes = P.par, *weights = P.par + n1m;                          // 0-based here
+    // LDS: UL[VS] | xl[VS] | wl[VS] | xr[VS] | wr[VS] | ring L[64] | ring R[64]
+    const int VS = ((m + 7) & ~7) + 8;
+    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *xr = wl + VS, *wr = xr + VS, *ringL = wr + VS, *ringR = ringL + 64;
+    const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
+    const double *TLg = P.deTL + (size_t)g * tsz + (size_t)pl * NP, *TRg = P.deTR + (size_t)g * tsz + (size_t)qr * NP;
+    const double *ULg = P.deUL + ((size_t)g * P.RM + pl) * (m + 1);
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    for (int x = lane; x < A; x += 64) { const int ix = Lt[(size_t)x * P.RM + pl] - 1; xl[x] = nodes[ix]; wl[x] = weights[ix]; }
+    for (int x = lane; x < B; x += 64) { const int ix = Rt[(size_t)x * P.RM + qr] - 1; xr[x] = nodes[ix]; wr[x] = weights[ix]; }
+    for (int x = lane; x <= A; x += 64) UL[x] = ULg[x];
+    const int i1 = iscol ? (live ? vmode : 0) : cur.jj - 1, i2 = iscol ? cur.kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
+    const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
+    WStream sl, sr;
+    sl.init(TLg, A * (A + 1) / 2, ringL, lane);
+    sr.init(TRg, B * (B + 1) / 2, ringR, lane);
+    __syncthreads();
+    // ---- pair product (test_crs_ising.f90:186-195), order of de_pairs_tab ----
+    double a = 1.0;
+    for (int i = 0; i <= A; i++) {
+        a = sl.chain(a, A - i, lane);
+        double u = UL[i];
+        u = u * x1; a = a * de_t2<FAST>(u);
+        de_run<FAST>(a, u, x2, xr, B);
+    }
+    de_run<FAST>(a, 1.0, x2, xr, B);                                   // i = A+1: starts after dim p
+    a = sr.chain(a, B * (B + 1) / 2, lane);
+    // ---- b-part (id 2) and the weights (:197-218), order of de_finish ----
+    const int id = P.ising_id;
+    double b = 0.0;
+    if (id == 2) {
+        double v = 1.0, ww = 1.0, vk = 1.0, wk = 1.0;
+        for (int j = B - 1; j >= 0; j--) { vk = vk * xr[j]; v = v + vk; }
+        vk = vk * x2; v = v + vk;
+        vk = vk * x1; v = v + vk;
+        for (int j = A - 1; j >= 0; j--) { vk = vk * xl[j]; v = v + vk; }
+        for (int j = 0; j < A; j++) { wk = wk * xl[j]; ww = ww + wk; }
+        wk = wk * x1; ww = ww + wk;
+        wk = wk * x2; ww = ww + wk;
+        for (int j = 0; j < B; j++) { wk = wk * xr[j]; ww = ww + wk; }
+        b = 1.0 / (v * ww);
+    }
+    double f = (id == 2) ? 2 * a * b : 2 * a;
+    for (int j = 0; j < A; j++) f = f * wl[j];
+    f = f * w1; f = f * w2;
+    for (int j = 0; j < B; j++) f = f * wr[j];
+    a = f;
+    // ---- fiber store, amax, residual, arg-max: as k_halfstep, on the fiber's linear index t ----
+    const int u_ = iscol ? pv : vmode, v_ = iscol ? vmode : pv;        // col: (i, j) ; row: (k, q), 0-based
+    const int t = iscol ? (u_ + r0 * v_) : (u_ + n2 * v_);
+    if (live) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
+    const double mx = wave_max(live ? fabs(a) : 0.0);
+    if (lane == 0 && mode != 1) atomic_max_pos(&gs.amax, mx);          // :531 / :564 (the piv = 0 branch :492-513 does not touch amax)
+    if (resid) {
+        const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+        double bb = a, ab = -1.0; int bi = INT_MAX;
+        if (live) {
+            if (iscol) {   // dgemv 'n', alpha=-1 (:538): b += (-x_s) * col(:, s), x_s = row(p+1)(s, kk, qq)
+                const double *c = Cp + u_ + (size_t)P.RM * v_;
+                const double *xq = Wq + (cur.kk - 1) + (size_t)P.NM * (cur.qq - 1);
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) bb = bb + (-xq[P.SW * s]) * c[P.SS * s];
+            } else {       // dgemv 't', alpha=-1 (:571): b += -1 * sum_s row(s, kq) * x_s, x_s = col(p)(ii, jj, s)
+                const double *wv = Wq + u_ + (size_t)P.NM * v_;
+                const double *xc = Cp + (cur.ii - 1) + (size_t)P.RM * (cur.jj - 1);
+                double tt = 0.0;
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) tt = tt + wv[P.SW * s] * xc[P.SS * s];
+                bb = bb + (-1.0) * tt;
+            }
+            ab = fabs(bb); bi = t;
+        }
+        wave_argmax(ab, bb, bi);
+        if (lane == 0) { Partial pr; pr.absmax = ab; pr.val = bb; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][w] = pr; }
+    }
+}

@@ -40,6 +40,7 @@ struct StepState {
     int ii, jj, kk, qq;    // current pivot candidate (1-based, reference names)
     int done, havecol, haverow, crs;
     int pending;           // 0 none, 1 column residual partials pending, 2 row residual partials pending
+    int npart;             // number of partial arg-max records behind `pending`
     double pivot;
 };
 
@@ -86,8 +87,9 @@ struct DevProb {
     const int *n;              // [d+2], 1-based
     const double *par;
     const double *aux;
-    double *deTL, *deUL, *deTR;  // Ising D/E: per-bond pair-factor tables [G][de_npair][RM], [G][d+1][RM], [G][de_npair][RM] (k_de_tables)
+    double *deTL, *deUL, *deTR;  // Ising D/E: per-bond pair-factor tables [G][RM][de_npair], [G][RM][d+1], [G][RM][de_npair] (k_de_tables)
     int de_npair;
+    int de_unit;                 // all nodes of par lie in [0,1]: the exact short division fdiv_unit applies
     const double *auxT;        // mvn: inv_cov transposed, auxT[j + d*i] = inv_cov(i,j) (same values, row walk contiguous)
     const double *quadw;       // [d+1][NM] padded, 1-based core index
     double *arg, *col, *row;   // [G][NC][CS]
@@ -140,5 +142,6 @@ struct DevProb {
     unsigned char *hreq;
     unsigned *cl_ctr;              // [G]
     int *cl_abort;                 // [1]
+    int cl_test_abort;             // test hook: block (group 0, block 0) raises the abort flag in launch number cl_test_abort (0: never)
     struct ClPart *cl_part;        // [2][G][TTX_CLMAX]
 };

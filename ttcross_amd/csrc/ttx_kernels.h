@@ -241,14 +241,40 @@ __device__ __forceinline__ void dims_asc(const short *pa, int A, int s1, int s2,
 template <int NS>
 __device__ __forceinline__ double de_finish(int id, double a, int m, int n1, const double *par, const short *pa, int A, int s1, int s2, const short *pb);
 
+// IEEE-exact fp64 division for operands in the "unit" range of the Ising integrands: with all nodes in [0,1] every
+// running product u lies in [0,1], so d = u+1 is in [1,2] and n = u-1 in [-1,0].  The compiler's a/b is
+// v_div_scale x2, v_rcp, 4 fma, mul, fma, v_div_fmas, v_div_fixup; for such operands neither v_div_scale rescales nor
+// does v_div_fixup change anything but the sign it would set anyway, so the Newton core alone -- the same v_rcp_f64 and
+// the same fused operations in the same order -- returns the identical bits with four instructions fewer.
+// (P.de_unit is set by the host only after checking the nodes; any other node set takes the plain division.)
+__device__ __forceinline__ double fdiv_unit(double n, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = n * r;
+    const double rem = __builtin_fma(-d, q, n);
+    return __builtin_fma(rem, r, q);
+}
+template <bool FAST>
+__device__ __forceinline__ double de_t2(double u)
+{   // ((u-1)/(u+1))^2, test_crs_ising.f90:190-191
+    const double n = u - 1.0, d = u + 1.0;
+    const double t = FAST ? fdiv_unit(n, d) : n / d;
+    return t * t;
+}
+
 // Pair product of an element (left pivot row il | s1 | s2 | right pivot row q) from the per-bond tables built by
 // k_de_tables: the factor ((u_ij-1)/(u_ij+1))^2 of a pair depends only on the dims i+1..j, so every pair that lies
 // entirely in the left pivot's dims (TL) or entirely in the right pivot's dims (TR) is shared by all elements through
 // that pivot and is only MULTIPLIED here -- in the reference's order, so the product is bit-identical; the IEEE
 // divisions are left for the pairs that span the bond (about a third of all pairs on average).
-// TLc / ULc / TRc point at the pivot's column of the [pair][RM] tables; rix[ro .. ro+B): the right pivot's index entries
-// (rix itself 16-byte aligned and padded).
-__device__ __forceinline__ double de_pairs_tab(int m, const double *nodes, int A, const double *TLc, const double *ULc, int RM,
+// TLc / ULc / TRc point at the pivot's own CONTIGUOUS row of the [pivot][pair] tables (this thread streams it);
+// rix[ro .. ro+B): the right pivot's index entries (rix itself 16-byte aligned and padded).
+template <bool FAST>
+__device__ __forceinline__ double de_pairs_tab(int m, const double *nodes, int A, const double *TLc, const double *ULc,
                                                int s1, int s2, const short *rix, int ro, const double *TRc)
 {
     const int B = m - A - 2;
@@ -256,23 +282,23 @@ __device__ __forceinline__ double de_pairs_tab(int m, const double *nodes, int A
     double a = 1.0;
     size_t pr = 0;
     auto run = [&](double u) {                          // the bond-spanning tail of a row: ... s2, right dims
-        auto step = [&](double xv) { u = u * xv; const double t = (u - 1.0) / (u + 1.0); a = a * (t * t); };
+        auto step = [&](double xv) { u = u * xv; a = a * de_t2<FAST>(u); };
         step(x2);
         seg_range(rix, ro, ro + B, nodes, step);
     };
     for (int i = 0; i <= A; i++) {
         const int cnt = A - i;
 #pragma unroll 8
-        for (int t = 0; t < cnt; t++) a = a * TLc[(pr + t) * RM];
+        for (int t = 0; t < cnt; t++) a = a * TLc[pr + t];
         pr += cnt;
-        double u = ULc[(size_t)i * RM];
-        u = u * x1; { const double t = (u - 1.0) / (u + 1.0); a = a * (t * t); }
+        double u = ULc[i];
+        u = u * x1; a = a * de_t2<FAST>(u);
         run(u);
     }
     run(1.0);                                           // i = A+1: starts after s1
     const size_t nr = (size_t)B * (B + 1) / 2;          // i >= A+2: pairs inside the right pivot's dims
 #pragma unroll 8
-    for (size_t t = 0; t < nr; t++) a = a * TRc[t * RM];
+    for (size_t t = 0; t < nr; t++) a = a * TRc[t];
     return a;
 }
 
@@ -524,8 +550,7 @@ __device__ __forceinline__ void atomic_max_pos(double *addr, double v)
 __device__ inline void resolve_state(StepState &c, const Partial *pt)
 {
     if (!c.active || !c.pending) return;
-    int nf = (c.pending == 1) ? c.r0 * c.n1 : c.n2 * c.r2;
-    int nb = (nf + TTX_BLK - 1) / TTX_BLK;
+    const int nb = c.npart;                      // records the half-step kernel wrote (its number of fiber workgroups)
     double ba = -1.0, bv = 0.0; int bi = INT_MAX;
     for (int b = 0; b < nb; b++) {
         double a = pt[b].absmax; int ix = pt[b].idx;
@@ -739,7 +764,7 @@ __device__ inline void bond_state(const DevProb &P, int g, int dir, int pp, Step
     }
     int nb = gs.last - gs.first + 1;
     st.active = (pp <= nb);
-    st.done = 0; st.havecol = 0; st.haverow = 0; st.crs = 0; st.pending = 0; st.pivot = 0.0;
+    st.done = 0; st.havecol = 0; st.haverow = 0; st.crs = 0; st.pending = 0; st.npart = 0; st.pivot = 0.0;
     st.ii = st.jj = st.kk = st.qq = 0;
     if (st.active) {
         int p = (dir == 1) ? gs.first + pp - 1 : gs.last + 1 - pp;   // :330-331
@@ -781,10 +806,11 @@ __global__ __launch_bounds__(256) void k_full_resolve(DevProb P)
 }
 
 // Ising D / E: per-bond tables of the pair factors that do not span the bond (see de_pairs_tab).  For every left
-// pivot c of bond p-1 (dims 1..A, A = p-1) and every start i: TL[(off(i) + j-i-1)*RM + c] = ((u-1)/(u+1))^2 with
-// u = x_{i+1}*...*x_j accumulated left to right (test_crs_ising.f90:188-192), UL[i*RM + c] = u after j = A; the same
-// for every right pivot of bond p+1 over its own dims (TR).  One thread per (start, pivot); pivot index fastest, so
-// the tables are written -- and later read by a column fiber -- coalesced.
+// pivot c of bond p-1 (dims 1..A, A = p-1) and every start i: TL[c*NP + off(i) + j-i-1] = ((u-1)/(u+1))^2 with
+// u = x_{i+1}*...*x_j accumulated left to right (test_crs_ising.f90:188-192), UL[c*(m+1) + i] = u after j = A; the
+// same for every right pivot of bond p+1 over its own dims (TR).  One thread per (start, pivot).  A pivot's factors are
+// CONTIGUOUS in the order in which an element through that pivot multiplies them, so that a wave whose elements share
+// the pivot (k_halfstep_de) streams them with coalesced 512-byte loads and a lone lane (lottery) walks its own row.
 __global__ __launch_bounds__(256) void k_de_tables(DevProb P, int dir, int pp)
 {
     const int g = blockIdx.y, m = P.d, RM = P.RM;
@@ -795,31 +821,31 @@ __global__ __launch_bounds__(256) void k_de_tables(DevProb P, int dir, int pp)
     const int *r = P.r + (size_t)g * (m + 2);
     const int r0 = r[p - 1], r2 = r[p + 1], A = p - 1, B = m - p - 1;
     const double *nodes = P.par - 1;
-    const size_t tsz = (size_t)P.de_npair * RM;
+    const size_t NP = (size_t)P.de_npair, tsz = NP * RM;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = x % RM, i = (x / RM) % (m + 1), side = x / (RM * (m + 1));
     if (side == 0) {
         if (c >= r0 || i > A) return;
         const short *Lt = L_ptr(P, g, p - 1, first);
-        double *TL = P.deTL + (size_t)g * tsz, *UL = P.deUL + (size_t)g * (m + 1) * RM;
+        double *TL = P.deTL + (size_t)g * tsz + (size_t)c * NP, *UL = P.deUL + ((size_t)g * RM + c) * (m + 1);
         const size_t off = (size_t)i * A - (size_t)i * (i - 1) / 2;
         double u = 1.0;
         for (int j = i + 1; j <= A; j++) {
             u = u * nodes[Lt[(size_t)(j - 1) * RM + c]];
             const double t = (u - 1.0) / (u + 1.0);
-            TL[(off + (j - i - 1)) * RM + c] = t * t;
+            TL[off + (j - i - 1)] = t * t;
         }
-        UL[(size_t)i * RM + c] = u;
+        UL[i] = u;
     } else if (side == 1) {
         if (c >= r2 || i >= B) return;
         const short *Rt = R_ptr(P, g, p + 1, first);
-        double *TR = P.deTR + (size_t)g * tsz;
+        double *TR = P.deTR + (size_t)g * tsz + (size_t)c * NP;
         const size_t off = (size_t)i * B - (size_t)i * (i - 1) / 2;
         double u = 1.0;
         for (int j = i + 1; j <= B; j++) {
             u = u * nodes[Rt[(size_t)(j - 1) * RM + c]];
             const double t = (u - 1.0) / (u + 1.0);
-            TR[(off + (j - i - 1)) * RM + c] = t * t;
+            TR[off + (j - i - 1)] = t * t;
         }
     }
 }
@@ -931,10 +957,12 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         if (usem) f = f_mvn_rows<2>(m, P.auxT, P.mvn_norm, DLv + (size_t)(i - 1) * VS, p - 1, par[j - 1] - P.aux[p - 1], par[k - 1] - P.aux[p],
                                     DRv + (size_t)(q - 1) * VS);
         else if (FUN == FUN_ISING && P.ising_id != 1 && P.deTL) {
-            const size_t tsz = (size_t)P.de_npair * P.RM;
-            const double *TL = P.deTL + (size_t)g * tsz, *UL = P.deUL + (size_t)g * (m + 1) * P.RM, *TR = P.deTR + (size_t)g * tsz;
+            const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
+            const double *TL = P.deTL + (size_t)g * tsz + (size_t)(i - 1) * NP, *UL = P.deUL + ((size_t)g * P.RM + (i - 1)) * (m + 1);
+            const double *TR = P.deTR + (size_t)g * tsz + (size_t)(q - 1) * NP;
             const short *pa_ = LT + (size_t)(i - 1) * VS, *pb_ = RT + (size_t)(q - 1) * VS;
-            const double ap = de_pairs_tab(m, par - 1, p - 1, TL + (i - 1), UL + (i - 1), P.RM, j, k, pb_, 0, TR + (q - 1));
+            const double ap = P.de_unit ? de_pairs_tab<true>(m, par - 1, p - 1, TL, UL, j, k, pb_, 0, TR)
+                                        : de_pairs_tab<false>(m, par - 1, p - 1, TL, UL, j, k, pb_, 0, TR);
             f = de_finish<2>(P.ising_id, ap, m, P.n[1], par, pa_, p - 1, j, k, pb_);
         } else {
             Src4 sx{LT + (size_t)(i - 1) * VS, p - 1, j, k, RT + (size_t)(q - 1) * VS};
@@ -1094,14 +1122,14 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             if (iscol) { const double *rn = vbase + (size_t)u * 2 * VS; a = f_ising_c3v(m, p - 1, rn, rn + VS, par[v], par[n1m + v], fn, fw); }
             else       { const double *rn = vbase + (size_t)v * 2 * VS; a = f_ising_c3v(m, p, fn, fw, par[u], par[n1m + u], rn, rn + VS); }
         } else if (FUN == FUN_ISING && P.ising_id != 1 && P.deTL) {
-            const size_t tsz = (size_t)P.de_npair * P.RM;
-            const double *TL = P.deTL + (size_t)g * tsz, *UL = P.deUL + (size_t)g * (m + 1) * P.RM, *TR = P.deTR + (size_t)g * tsz;
+            const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
+            const double *TL = P.deTL + (size_t)g * tsz, *UL = P.deUL + (size_t)g * P.RM * (m + 1), *TR = P.deTR + (size_t)g * tsz;
             double pa_;
             if (iscol) {     // left pivot u varies, s1 = v+1, s2 = kk, right pivot qq fixed (fxs = [kk, right dims])
-                pa_ = de_pairs_tab(m, par - 1, p - 1, TL + u, UL + u, P.RM, v + 1, cur.kk, fxs, 1, TR + (cur.qq - 1));
+                pa_ = de_pairs_tab<false>(m, par - 1, p - 1, TL + (size_t)u * NP, UL + (size_t)u * (m + 1), v + 1, cur.kk, fxs, 1, TR + (size_t)(cur.qq - 1) * NP);
                 a = de_finish<1>(P.ising_id, pa_, m, n1m, par, vt + (size_t)u * VS, p - 1, v + 1, 0, fxs);
             } else {         // left pivot ii fixed (fxs = [left dims, jj]), s1 = jj, s2 = u+1, right pivot v varies
-                pa_ = de_pairs_tab(m, par - 1, p - 1, TL + (cur.ii - 1), UL + (cur.ii - 1), P.RM, cur.jj, u + 1, vt + (size_t)v * VS, 0, TR + v);
+                pa_ = de_pairs_tab<false>(m, par - 1, p - 1, TL + (size_t)(cur.ii - 1) * NP, UL + (size_t)(cur.ii - 1) * (m + 1), cur.jj, u + 1, vt + (size_t)v * VS, 0, TR + (size_t)v * NP);
                 a = de_finish<1>(P.ising_id, pa_, m, n1m, par, fxs, p, u + 1, 0, vt + (size_t)v * VS);
             }
         } else if (usem) {
@@ -1158,6 +1186,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
         StepState nx = cur;
         nx.crs = crs; nx.havecol = havecol; nx.haverow = haverow; nx.done = done;
         nx.pending = resid ? (iscol ? 1 : 2) : 0;
+        nx.npart = (nf + TTX_BLK - 1) / TTX_BLK;
         gs.S[h + 1] = nx;
         if (mode != 2) gs.neval += nf;                                        // :527 / :560 / :509
         // algorithmic traffic: factor slabs + vector + fiber in/out when a residual is taken, else the fiber

@@ -290,6 +290,20 @@ class TTCross:
         L.ttx_sweep_path.argtypes = [c_void_p]
         return ("chain", "fused", "cluster")[L.ttx_sweep_path(self._h)]
 
+    @property
+    def resid_halfsteps(self):
+        L = load_library()
+        L.ttx_resid_halfsteps.argtypes = [c_void_p]
+        L.ttx_resid_halfsteps.restype = c_int64
+        return int(L.ttx_resid_halfsteps(self._h))
+
+    @property
+    def cluster_fallbacks(self):
+        """Runs replayed on the chain path after a wait inside the cluster sweep kernel timed out (include/ttx.h)."""
+        L = load_library()
+        L.ttx_cluster_fallbacks.argtypes = [c_void_p]
+        return int(L.ttx_cluster_fallbacks(self._h))
+
     def set_profile(self, on=True):
         _check(load_library().ttx_set_profile(self._h, 1 if on else 0))
 
@@ -454,3 +468,12 @@ def exp_host(x):
     out = np.zeros_like(x)
     _check(load_library().ttx_exp_host(x.size, _dp(x), _dp(out)))
     return out
+
+
+def k_latency_probe(device=0):
+    """dict of unit latencies in ns measured on one wave (include/ttx.h: ttx_k_latency_probe)."""
+    L = load_library()
+    L.ttx_k_latency_probe.argtypes = [c_int32, POINTER(c_double)]
+    o = (c_double * 5)()
+    _check(L.ttx_k_latency_probe(device, o))
+    return dict(fp64_mul_ns=o[0], fp64_mul_add_ns=o[1], l2_roundtrip_ns=o[2], lds_read_ns=o[3], fp64_div_ns=o[4])
