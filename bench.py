@@ -31,7 +31,10 @@ WORKLOADS = {
     "d32": (("ising", "d", 32, 51, 24, 2), "Ising D_32 n=51 r=24 piv=2 (d=31)"),
     # BASELINE config 5 at full size: about 12 s per step on one MI355X (use --steps 1 --warmup 0 --no-cpu-baseline)
     "d256": (("ising", "d", 256, 101, 64, 5), "Ising D_256 n=101 r=64 piv=5 (d=255)"),
+    # BASELINE config 4 at full size (4 bond groups by default): about 3 s per step
+    "mvn128": (("mvn", "mvn", 128, 33, 50, 2), "mvn d=128 n=33 r=50 piv=2 (multivariate-normal density, test_crs_mvn)"),
 }
+LONG_WORKLOADS = {"d256", "mvn128"}     # one CPU run takes minutes: cpu_baseline times a bounded prefix of one run
 FP64_VECTOR_PEAK_TFLOPS = 78.0      # MI355X fp64 vector (non-matrix) peak, SURVEY 8(d)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -106,6 +109,57 @@ def cpu_baseline(argv, groups, budget_s=24.0):
     return (multi or single), single
 
 
+def cpu_baseline_prefix(argv, limit_s=None):
+    """Workloads whose CPU run takes minutes (D_256: 474 s, mvn 128: 51 s on 8 cores): the genuine reference is started on all
+    host cores of this box and stopped after limit_s; the rate is n_evals / time of the last per-sweep line it printed
+    (lib/dmrgg.f90:971-1008).  The cost per evaluation does not depend on the sweep, so the prefix rate stands for the run."""
+    import signal
+    cores = min(os.cpu_count() or 1, 64)
+    if limit_s is None:      # mvn: the whole run fits (its low-rank sweeps are fork/join-bound, a short prefix would flatter the GPU)
+        limit_s = 30.0 if argv[0] == "ising" else 100.0
+    if argv[0] == "ising":
+        cmd = [os.path.join(ROOT, "oracle", "_ref", "test_crs_ising"), argv[1].upper()] + [str(x) for x in argv[2:]]
+    else:
+        cmd = [os.path.join(ROOT, "oracle", "_ref", "test_crs_mvn")] + [str(x) for x in argv[2:]]
+    if not os.path.exists(cmd[0]):
+        return None
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_THREADING_LAYER="SEQUENTIAL", OMP_PROC_BIND="close")
+    last = None
+    try:
+        import pty
+        import select
+        mfd, sfd = pty.openpty()          # a terminal, so that the Fortran run time flushes every line
+        p = subprocess.Popen(cmd, stdout=sfd, stderr=subprocess.DEVNULL, env=env)
+        os.close(sfd)
+        t0 = time.time()
+        buf = ""
+        while time.time() - t0 < limit_s and p.poll() is None:
+            if select.select([mfd], [], [], 0.5)[0]:
+                try:
+                    buf += os.read(mfd, 65536).decode(errors="replace")
+                except OSError:
+                    break
+                *lines, buf = buf.split("\n")
+                for line in lines:
+                    mm = re.search(r"time:\s*([0-9.E+-]+)\s+n_evals:\s*(\d+)", line)
+                    if mm and float(mm.group(1)) > 0:
+                        last = (int(mm.group(2)), float(mm.group(1)), line.split()[0])
+        if p.poll() is None:
+            p.send_signal(signal.SIGTERM)
+            try:
+                p.wait(timeout=10)
+            except Exception:  # noqa: BLE001
+                p.kill()
+        os.close(mfd)
+    except Exception:  # noqa: BLE001
+        return None
+    if not last:
+        return None
+    return {"value": last[0] / last[1], "unit": "evals/s", "cores": cores, "kind": "reference",
+            "sample": f"the first {last[1]:.1f} s of {' '.join(os.path.basename(c) if i == 0 else c for i, c in enumerate(cmd))} (genuine reference, amdflang -O2 -fopenmp + MKL sequential, "
+                      f"OMP_NUM_THREADS={cores}): {last[0]} evaluations up to sweep {last[2]}"}
+
+
 def tt_own(nproc, d):
     """share(1, d-1, nproc) of lib/default.f90:78-97: own(0:nproc)."""
     first, last = 1, d - 1
@@ -151,11 +205,11 @@ def main():
     from ttcross_amd import engine as E
 
     argv, desc = WORKLOADS[a.workload]
-    s = D.ising_setup(argv[1], argv[2], argv[3])
-    groups = a.groups or max(8, world)
-    tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
+    s = D.ising_setup(argv[1], argv[2], argv[3]) if argv[0] == "ising" else D.box_setup(argv[0], argv[2], argv[3])
+    groups = a.groups or max(4 if a.workload == "mvn128" else 8, world)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
                    nproc=groups, device=local, world_rank=rank, world_size=world) if world > 1 else \
-        E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
+        E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
                   nproc=groups, device=local)
     transport = "none (single process)"
     if world > 1:
@@ -176,7 +230,7 @@ def main():
             transport = "rccl (ncclSend/ncclRecv + ncclAllReduce over xGMI)"
         else:
             tt.close()
-            tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
+            tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
                            nproc=groups, device=local, world_rank=rank, world_size=world)
             if a.backend == "nccl" and gloo_pg is None:
                 raise SystemExit("neither the RCCL transport nor a gloo fallback group is available")
@@ -233,7 +287,7 @@ def main():
               "factor_bytes": 8 * m_rows * r_cols, "avg_launch_us": 1e3 * ms, "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS}
         if groups != 1:
-            t1 = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
+            t1 = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
                            nproc=1, device=local)
             t1.run()
             tb = time.perf_counter()
@@ -272,7 +326,7 @@ def main():
         "value": neval / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (integrand evaluated on the fly; Gauss-Legendre nodes/weights; flang-compatible lottery RNG stream)",
-        "config": {"workload": desc, "driver": "test_crs_ising " + " ".join(str(x) for x in argv[1:]), "bond_groups": groups, "transport": transport,
+        "config": {"workload": desc, "driver": ("test_crs_ising " + " ".join(str(x) for x in argv[1:])) if argv[0] == "ising" else ("test_crs_mvn " + " ".join(str(x) for x in argv[2:])), "bond_groups": groups, "transport": transport,
                    "neval_per_step": neval // a.steps, "sweeps": nsweeps, "integral": value,
                    "rel_err_vs_analytic": abs(1 - value / s["tru"]) if s["tru"] else None},
         "roofline": {"kernel": kdesc, "bound": "hbm", "achieved": achieved,
@@ -283,7 +337,7 @@ def main():
     }
     # K1 (fiber evaluation) as fp64 vector work, SURVEY 8(d): algorithmic flops per evaluation of the integrand
     dd = len(s["n"])
-    fl = (5 * dd + 1) if argv[1] == "c" else (6 * dd * (dd + 1) // 2 + 5 * dd)
+    fl = (5 * dd + 1) if argv[1] == "c" else (2 * dd * dd + dd + 20) if argv[0] == "mvn" else (6 * dd * (dd + 1) // 2 + 5 * dd)
     out["k1_evaluation"] = {"flops_per_eval": fl, "achieved": (neval / dt) * fl / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": (neval / dt) * fl / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
     # The HBM roofline is the wrong yardstick for the sweep kernel at BASELINE sizes (a launch moves 3.8 MB in ~300 us): what
@@ -323,8 +377,12 @@ def main():
     if one_group:
         out["single_group"] = one_group
     if not a.no_cpu_baseline and world == 1:
-        out["cpu_baseline"], out["cpu_baseline_single"] = cpu_baseline(argv, groups)
-        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if a.workload in LONG_WORKLOADS:
+            out["cpu_baseline"] = cpu_baseline_prefix(argv)
+        else:
+            out["cpu_baseline"], out["cpu_baseline_single"] = cpu_baseline(argv, groups)
+        if out["cpu_baseline"]:
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
 
 

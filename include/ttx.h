@@ -92,6 +92,10 @@ typedef struct ttx_transport {
     int (*allreduce)(void *ctx, double *buf, int64_t count, int op);
 } ttx_transport;
 int ttx_set_transport(ttx_engine *h, const ttx_transport *t);
+/* Built-in host transport for processes of ONE node, over a POSIX shared-memory segment `name` (every rank passes the same
+ * name; rank 0 creates it): the same two primitives, no MPI and no RCCL needed.  Used by the Fortran drop-in layer
+ * (TTX_TRANSPORT=shm) and by tests that run several engine processes on one GPU, where RCCL cannot. */
+int ttx_comm_init_shm(ttx_engine *h, const char *name);
 
 /* The reference's integrand callback, `double precision,external :: fun` called as fun(m, ind, n, par) (lib/dmrgg.f90:18,
  * walked by dmrgg_fun :1053-1078): Fortran calling convention, everything by reference; ind and n are default integers.

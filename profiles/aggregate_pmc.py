@@ -14,7 +14,7 @@ def short(name):
 
 
 def main():
-    print("pass,kernel,counter,launches,sum_KB,mean_KB_per_launch")
+    print("pass,kernel,counter,launches,sum,mean_per_launch")   # FETCH_SIZE / WRITE_SIZE are in KB, SQ_* counters in their own units
     for arg in sys.argv[1:]:
         tag, d = arg.split(":", 1)
         files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)

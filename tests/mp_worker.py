@@ -5,6 +5,7 @@ transport is the one the 8-GPU job runs.  Rank 0 checks the job against the orac
 bond groups; every rank checks the cores it holds.  Exit code != 0 on any mismatch.
 
     python -m torch.distributed.run --nproc-per-node W tests/mp_worker.py KIND M N R PIV NGROUPS [gloo|rccl]
+    RANK=r WORLD_SIZE=W TTX_SHM_NAME=x python tests/mp_worker.py KIND M N R PIV NGROUPS shm     (one process per rank, no torch)
 """
 import os
 import sys
@@ -17,14 +18,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
-    import torch
-    import torch.distributed as dist
     kind, m, n, r, piv, ng = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
     transport = sys.argv[7] if len(sys.argv) > 7 else "gloo"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    ndev = torch.cuda.device_count()
-    dev = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)
-    dist.init_process_group("gloo")
+    dist = None
+    dev = 0
+    if transport != "shm":
+        import torch
+        import torch.distributed as dist
+        ndev = torch.cuda.device_count()
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)
+        dist.init_process_group("gloo")
     import oracle_lib as O
     from ttcross_amd import drivers as D
     from ttcross_amd import engine as E
@@ -33,6 +37,8 @@ def main():
                    nproc=ng, device=dev, world_rank=rank, world_size=world)
     if transport == "rccl":
         tt.comm_init(dist)
+    elif transport == "shm":
+        tt.comm_init_shm(os.environ.get("TTX_SHM_NAME", "ttx_test"))
     else:
         tt.set_dist_transport(dist)
     tt.run()
@@ -62,9 +68,11 @@ def main():
             if not np.array_equal(tt.core(k), oo["cores"][k - 1]):
                 bad.append(f"core{k}")
     print(f"[rank {rank}/{world}] groups={ng} transport={transport} value={val:.16e} neval={tt.neval} cores_held={ncores} "
-          f"time={tt.seconds*1e3:.2f}ms {'OK' if not bad else 'MISMATCH ' + '; '.join(bad[:6])}", flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+          f"path={tt.sweep_path()} time={tt.seconds*1e3:.2f}ms {'OK' if not bad else 'MISMATCH ' + '; '.join(bad[:6])}", flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    tt.close()
     sys.exit(1 if bad else 0)
 
 

@@ -257,6 +257,75 @@ def test_multi_process_bond_split(world, args):
     assert out.stdout.count(" OK") == world
 
 
+def _spawn_ranks(world, argv, extra_env=None, timeout=600):
+    """`world` processes with RANK / WORLD_SIZE (and the TTX_WORLD_* twins the Fortran layer reads), a fresh shm name each."""
+    import os
+    import subprocess
+    import uuid
+    name = "ttx_" + uuid.uuid4().hex[:12]
+    procs = []
+    for rk in range(world):
+        env = dict(os.environ, RANK=str(rk), WORLD_SIZE=str(world), TTX_WORLD_RANK=str(rk), TTX_WORLD_SIZE=str(world),
+                   TTX_SHM_NAME=name, TTX_TRANSPORT="shm", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    return outs
+
+
+@pytest.mark.parametrize("world,args,pipeline", [(2, "c 6 33 20 2 4", "1"), (2, "c 64 51 32 2 8", "1"), (3, "d 8 33 10 2 3", "1"), (4, "c 16 51 32 2 8", "1"),
+                                                 (2, "c 64 51 32 2 8", "0")],
+                         ids=["w2_c6_g4", "w2_c64_g8", "w3_d8_g3", "w4_c16_g8", "w2_c64_g8_hostsync"])
+def test_multi_process_shm_transport(world, args, pipeline):
+    """The N>1 path without torch or MPI: `world` engine processes on this one card over the engine's built-in
+    shared-memory transport (RCCL refuses several ranks on one device).  The exchange is stream-ordered (host functions in
+    the engine's stream), so the Ising C cases run the PIPELINED loop with the cluster kernel -- the control flow of the
+    multi-GPU job -- and must be bit-identical to the oracle's virtual ranks; once more with the host-synchronised loop."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = _spawn_ranks(world, [sys.executable, os.path.join(root, "tests", "mp_worker.py")] + args.split() + ["shm"], {"TTX_PIPELINE": pipeline})
+    for rc, o, e in outs:
+        assert rc == 0 and " OK" in o, o[-2000:] + e[-2000:]
+
+
+@pytest.mark.parametrize("world,name", [(2, "ising_C_6_33_20_2_np4"), (4, "ising_C_6_33_20_2_np4"), (2, "ising_C_16_51_32_2_np8")])
+def test_fortran_driver_multi_process(world, name):
+    """The Fortran drop-in as a multi-process job (one process per GPU in production; here the ranks share the card):
+    TTX_WORLD_RANK / TTX_WORLD_SIZE, bond groups by TTX_NGROUPS, transport TTX_TRANSPORT=shm.  Rank 0 prints the
+    reference's log -- compared with the golden log of the reference under mpiexec -np <groups> (patched build)."""
+    import os
+    from conftest import fortran_exe
+    from golden_util import GOLDEN, parse_log
+    exe = fortran_exe("test_crs_ising")
+    t = name.split("_")
+    ng = int(t[-1][2:])
+    outs = _spawn_ranks(world, [exe] + t[1:-1], {"TTX_NGROUPS": str(ng)})
+    for rc, o, e in outs:
+        assert rc == 0, o[-2000:] + e[-2000:]
+    g_rows, g_val, g_nev = parse_log(open(os.path.join(GOLDEN, name + ".txt")).read())
+    o_rows, o_val, o_nev = parse_log(outs[0][1])
+    assert len(g_rows) == len(o_rows)
+    need = 17 if "C_6" in name else 18                 # as tests/test_oracle_golden.py for these logs
+    k = 0
+    for a, b in zip(g_rows, o_rows):
+        if a["erank"] == b["erank"] and a["neval"] == b["neval"] and abs(a["val"] - b["val"]) <= 2e-13 * abs(a["val"]):
+            k += 1
+        else:
+            break
+    assert k >= need, f"only {k} leading sweeps match the reference (need {need})"
+    assert abs(g_val - o_val) <= 1e-13 * abs(g_val)
+    assert all(len(parse_log(o)[0]) == 0 for _, o, _ in outs[1:]), "only rank 0 prints the sweep log"
+
+
 @pytest.mark.parametrize("name", ["ising_C_6_33_20_2", "ising_C_8_25_12_3", "ising_D_6_33_12_2", "ising_C_5_17_8_0", "ising_C_16_33_24_0"])
 def test_fortran_dropin_driver_matches_reference_log(name):
     """The Fortran drop-in layer (ttcross_amd/fortran: modules named like the reference's, drivers with the

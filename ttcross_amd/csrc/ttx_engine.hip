@@ -20,7 +20,12 @@
 #include <thread>
 #include <vector>
 
+#include <atomic>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>   // types and enums only: the library is dlopen()ed by ttx_comm_init
 
 #include "../../include/ttx.h"
@@ -94,6 +99,21 @@ struct ttx_engine {
     ncclComm_t comm = nullptr;
     ttx_transport cb{};
     bool have_cb = false;
+    int cb_error = 0;                   // set by a failed host-function transfer (checked at the next host synchronisation)
+    // staging of host-transport all-reduces: a ring of pinned slots, one per reduction in flight
+    struct RedJob { ttx_engine *h; double *buf; size_t count; int op; };
+    static const int NRED = 16;
+    RedJob red[NRED];
+    double *red_mem = nullptr; size_t red_cap = 0; int red_next = 0;
+    RedJob *red_slot(size_t count, int op)
+    {
+        if (!red_mem || count > red_cap) return nullptr;
+        RedJob *j = &red[red_next];
+        j->h = this; j->buf = red_mem + (size_t)red_next * red_cap; j->count = count; j->op = op;
+        red_next = (red_next + 1) % NRED;
+        return j;
+    }
+    struct ShmTransport *shm = nullptr; // built-in node-local transport (ttx_comm_init_shm)
     std::vector<ttx_sweep_rec> recs;
     std::vector<int32_t> tapes;         // [nsweeps-1][d+1][4]
     std::vector<int32_t> rfinal;
@@ -420,6 +440,10 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     for (int x = 0; x < 2; x++) { HIPCHECK(hipEventCreateWithFlags(&h->ev_sum[x], hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_val[x], hipEventDisableTiming)); }
     HIPCHECK(hipHostMalloc((void **)&h->h_msg, 4 * P.MSZ));
     HIPCHECK(hipHostMalloc((void **)&h->h_tmp, sizeof(double) * std::max(h->QB, h->SB)));
+    if (W > 1) {
+        h->red_cap = std::max<size_t>(std::max(h->QB, h->SB), 8);
+        HIPCHECK(hipHostMalloc((void **)&h->red_mem, sizeof(double) * h->red_cap * ttx_engine::NRED));
+    }
     {   // lottery CDF segment tables for every K that can occur (K <= maxrank*n): pure function of K, see ttx_cdf.h
         const int kmax = h->RM * NM;
         if (kmax <= 16384) {
@@ -545,6 +569,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
 }
 extern "C" int ttx_create(ttx_engine **out, const ttx_config *cfg) { return create_impl(out, cfg, false); }
 
+static void shm_close(ttx_engine *h);
 extern "C" void ttx_destroy(ttx_engine *h)
 {
     if (!h) return;
@@ -556,6 +581,8 @@ extern "C" void ttx_destroy(ttx_engine *h)
     for (int x = 0; x < 2; x++) { if (h->ev_sum[x]) (void)hipEventDestroy(h->ev_sum[x]); if (h->ev_val[x]) (void)hipEventDestroy(h->ev_val[x]); }
     if (h->h_msg) (void)hipHostFree(h->h_msg);
     if (h->h_tmp) (void)hipHostFree(h->h_tmp);
+    if (h->red_mem) (void)hipHostFree(h->red_mem);
+    shm_close(h);
     if (h->h_abort) (void)hipHostFree(h->h_abort);
     if (h->P.hidx) (void)hipHostFree(h->P.hidx);
     if (h->P.hval) (void)hipHostFree(h->P.hval);
@@ -587,6 +614,136 @@ extern "C" int ttx_comm_init(ttx_engine *h, const uint8_t id[128])
     NCCLCHECK(g_rccl.CommInitRank(&h->comm, h->W, u, h->wrank));
     return TTX_OK;
 }
+// ---- built-in node-local host transport over POSIX shared memory ------------------------------------------------
+// For jobs whose processes share a node but cannot use RCCL (several ranks on ONE GPU -- RCCL refuses that -- or no
+// librccl), and for launchers without MPI (the Fortran drop-in layer): the ttx_transport primitives implemented on a
+// shared segment.  Point-to-point: one mailbox per (receiver, side) with a sequence / acknowledge pair; all-reduce: every
+// rank deposits its vector, a sense-reversing barrier, every rank folds the W vectors in rank order (so all ranks get
+// the identical bits), a second barrier before the slots are reused.  Waits are bounded (60 s) and report failure.
+struct ShmHeader {
+    std::atomic<uint32_t> ready, arrived, sense;
+    uint32_t W; uint64_t msz, redcap;
+};
+struct ShmBox { std::atomic<uint64_t> seq, ack; uint64_t bytes; };
+struct ShmTransport {
+    void *base = nullptr; size_t size = 0; std::string name; int rank = 0, W = 1; bool owner = false;
+    ShmHeader *hd = nullptr;
+    size_t msz = 0, redcap = 0;
+    uint32_t my_sense = 0;
+    ShmBox *box(int r, int side) const { return (ShmBox *)((char *)base + 4096 + ((size_t)r * 2 + side) * (64 + msz)); }   // side 0: from the left, 1: from the right
+    char *boxdata(int r, int side) const { return (char *)box(r, side) + 64; }
+    double *red(int r) const { return (double *)((char *)base + 4096 + (size_t)W * 2 * (64 + msz) + (size_t)r * redcap * sizeof(double)); }
+};
+static bool shm_wait(const std::function<bool()> &cond)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (cond()) return true;
+        if ((spins & 1023u) == 1023u) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) return false;
+            std::this_thread::yield();
+        }
+    }
+}
+static int shm_barrier(ShmTransport *T)
+{
+    T->my_sense ^= 1u;
+    if (T->hd->arrived.fetch_add(1u, std::memory_order_acq_rel) + 1u == (uint32_t)T->W) {
+        T->hd->arrived.store(0u, std::memory_order_relaxed);
+        T->hd->sense.store(T->my_sense, std::memory_order_release);
+        return 0;
+    }
+    return shm_wait([&] { return T->hd->sense.load(std::memory_order_acquire) == T->my_sense; }) ? 0 : 1;
+}
+static int shm_sendrecv(void *ctx, int to, const void *sbuf, int64_t ns, int from, void *rbuf, int64_t nr)
+{
+    ShmTransport *T = (ShmTransport *)ctx;
+    if ((size_t)ns > T->msz || (size_t)nr > T->msz) return 1;
+    if (to >= 0) {                                   // I am the left neighbour of `to` when to == rank + 1: its side-0 box
+        const int side = (to == T->rank + 1) ? 0 : 1;
+        ShmBox *b = T->box(to, side);
+        if (!shm_wait([&] { return b->ack.load(std::memory_order_acquire) == b->seq.load(std::memory_order_relaxed); })) return 1;
+        memcpy(T->boxdata(to, side), sbuf, (size_t)ns);
+        b->bytes = (uint64_t)ns;
+        b->seq.fetch_add(1u, std::memory_order_release);
+    }
+    if (from >= 0) {
+        const int side = (from == T->rank - 1) ? 0 : 1;
+        ShmBox *b = T->box(T->rank, side);
+        if (!shm_wait([&] { return b->seq.load(std::memory_order_acquire) != b->ack.load(std::memory_order_relaxed); })) return 1;
+        memcpy(rbuf, T->boxdata(T->rank, side), (size_t)std::min<uint64_t>((uint64_t)nr, b->bytes));
+        b->ack.fetch_add(1u, std::memory_order_release);
+    }
+    return 0;
+}
+static int shm_allreduce(void *ctx, double *buf, int64_t count, int op)
+{
+    ShmTransport *T = (ShmTransport *)ctx;
+    if ((size_t)count > T->redcap) return 1;
+    memcpy(T->red(T->rank), buf, sizeof(double) * (size_t)count);
+    if (shm_barrier(T)) return 1;
+    for (int64_t i = 0; i < count; i++) {
+        double a = T->red(0)[i];
+        for (int r = 1; r < T->W; r++) a = op ? std::max(a, T->red(r)[i]) : a + T->red(r)[i];
+        buf[i] = a;
+    }
+    return shm_barrier(T);
+}
+static void shm_close(ttx_engine *h)
+{
+    ShmTransport *T = h->shm;
+    if (!T) return;
+    if (T->base) munmap(T->base, T->size);
+    if (T->owner) shm_unlink(T->name.c_str());
+    delete T;
+    h->shm = nullptr;
+}
+extern "C" int ttx_comm_init_shm(ttx_engine *h, const char *name)
+{
+    if (!h || !name || !*name) return fail(TTX_EINVAL, "ttx_comm_init_shm: null argument");
+    if (h->W == 1) return TTX_OK;
+    if (h->shm) return fail(TTX_ESTATE, "ttx_comm_init_shm: already initialised");
+    ShmTransport *T = new ShmTransport();
+    T->name = std::string(name[0] == '/' ? "" : "/") + name;
+    T->rank = h->wrank; T->W = h->W;
+    T->msz = (h->P.MSZ + 63) & ~(size_t)63;
+    T->redcap = std::max<size_t>(std::max(h->QB, h->SB), 8);
+    T->size = 4096 + (size_t)T->W * 2 * (64 + T->msz) + (size_t)T->W * T->redcap * sizeof(double);
+    int fd = -1;
+    if (T->rank == 0) {
+        shm_unlink(T->name.c_str());
+        fd = shm_open(T->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)T->size) != 0) { if (fd >= 0) close(fd); delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: cannot create %s", name); }
+        T->owner = true;
+    } else {
+        const bool ok = shm_wait([&] {
+            fd = shm_open(T->name.c_str(), O_RDWR, 0600);
+            if (fd < 0) return false;
+            struct stat st;
+            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= T->size) return true;
+            close(fd); fd = -1;
+            return false;
+        });
+        if (!ok) { delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: rank 0 did not create %s", name); }
+    }
+    T->base = mmap(nullptr, T->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (T->base == MAP_FAILED) { T->base = nullptr; delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: mmap failed"); }
+    T->hd = (ShmHeader *)T->base;
+    if (T->rank == 0) {          // a fresh segment is zero-filled: sequence numbers, counters and the sense start at 0
+        T->hd->W = (uint32_t)T->W; T->hd->msz = T->msz; T->hd->redcap = T->redcap;
+        T->hd->ready.store(1u, std::memory_order_release);
+    } else {
+        if (!shm_wait([&] { return T->hd->ready.load(std::memory_order_acquire) == 1u; })) { munmap(T->base, T->size); delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: segment never became ready"); }
+        if (T->hd->W != (uint32_t)T->W || T->hd->msz != T->msz || T->hd->redcap != T->redcap) { munmap(T->base, T->size); delete T; return fail(TTX_EINVAL, "ttx_comm_init_shm: the ranks disagree about the problem"); }
+    }
+    h->shm = T;
+    h->cb.ctx = T; h->cb.sendrecv = shm_sendrecv; h->cb.allreduce = shm_allreduce; h->have_cb = true;
+    // everybody is attached before rank 0 may unlink the name at destroy time
+    if (shm_barrier(T)) return fail(TTX_EHIP, "ttx_comm_init_shm: not all %d ranks attached", T->W);
+    return TTX_OK;
+}
+
 extern "C" int ttx_set_transport(ttx_engine *h, const ttx_transport *t)
 {
     if (!h || !t || !t->sendrecv || !t->allreduce) return fail(TTX_EINVAL, "ttx_set_transport: null argument");
@@ -603,6 +760,22 @@ extern "C" int ttx_set_integrand_host(ttx_engine *h, ttx_host_fun fun, const dou
 }
 extern "C" int64_t ttx_host_calls(const ttx_engine *h) { return h ? h->host_calls : 0; }
 
+// host functions of the stream-ordered host transport (run on a runtime thread when the stream reaches them; no HIP calls)
+static void hostfn_xfer(void *ud)
+{
+    ttx_engine *h = (ttx_engine *)ud;
+    const DevProb &P = h->P;
+    const int left = (h->g0 > 0) ? h->wrank - 1 : -1, right = (h->g0 + h->G < h->cfg.nproc) ? h->wrank + 1 : -1;
+    char *sR = h->h_msg, *sL = h->h_msg + P.MSZ, *rL = h->h_msg + 2 * P.MSZ, *rR = h->h_msg + 3 * P.MSZ;
+    if (h->cb.sendrecv(h->cb.ctx, right, sR, (int64_t)P.MSZ, left, rL, (int64_t)P.MSZ)) h->cb_error = 1;
+    if (h->cb.sendrecv(h->cb.ctx, left, sL, (int64_t)P.MSZ, right, rR, (int64_t)P.MSZ)) h->cb_error = 1;
+}
+static void hostfn_allreduce(void *ud)
+{
+    ttx_engine::RedJob *j = (ttx_engine::RedJob *)ud;
+    if (j->h->cb.allreduce(j->h->cb.ctx, j->buf, (int64_t)j->count, j->op)) j->h->cb_error = 1;
+}
+
 // messages of the boundary groups to the neighbouring GPUs (device buffers; after k_exch_pack)
 static int xfer_neighbours(ttx_engine *h)
 {
@@ -618,14 +791,15 @@ static int xfer_neighbours(ttx_engine *h)
         return TTX_OK;
     }
     if (!h->have_cb) return fail(TTX_ESTATE, "world_size > 1 but neither ttx_comm_init nor ttx_set_transport was called");
-    char *sR = h->h_msg, *sL = h->h_msg + P.MSZ, *rL = h->h_msg + 2 * P.MSZ, *rR = h->h_msg + 3 * P.MSZ;
+    // Host transport, STREAM-ORDERED: device -> pinned copies, then a host function enqueued in the stream runs the two
+    // sendrecv calls, then pinned -> device copies.  The host thread that called ttx_run does not wait: the control flow
+    // (and therefore the pipelined sweep loop) is the same as with RCCL, only the primitive differs.
+    char *sR = h->h_msg, *sL = h->h_msg + P.MSZ;
     if (right >= 0) HIPCHECK(hipMemcpyAsync(sR, outR, P.MSZ, hipMemcpyDeviceToHost, h->stream));
     if (left >= 0) HIPCHECK(hipMemcpyAsync(sL, outL, P.MSZ, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    if (h->cb.sendrecv(h->cb.ctx, right, sR, (int64_t)P.MSZ, left, rL, (int64_t)P.MSZ)) return fail(TTX_EHIP, "transport sendrecv (right-going) failed");
-    if (h->cb.sendrecv(h->cb.ctx, left, sL, (int64_t)P.MSZ, right, rR, (int64_t)P.MSZ)) return fail(TTX_EHIP, "transport sendrecv (left-going) failed");
-    if (left >= 0) HIPCHECK(hipMemcpyAsync(h->recvL, rL, P.MSZ, hipMemcpyHostToDevice, h->stream));
-    if (right >= 0) HIPCHECK(hipMemcpyAsync(h->recvR, rR, P.MSZ, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipLaunchHostFunc(h->stream, hostfn_xfer, h));
+    if (left >= 0) HIPCHECK(hipMemcpyAsync(h->recvL, h->h_msg + 2 * P.MSZ, P.MSZ, hipMemcpyHostToDevice, h->stream));
+    if (right >= 0) HIPCHECK(hipMemcpyAsync(h->recvR, h->h_msg + 3 * P.MSZ, P.MSZ, hipMemcpyHostToDevice, h->stream));
     return TTX_OK;
 }
 // all-reduce of `count` doubles from device buffer src into device buffer dst; op 0 = sum, 1 = max
@@ -634,10 +808,12 @@ static int allreduce_dev(ttx_engine *h, const double *src, double *dst, size_t c
     if (h->W == 1) return TTX_OK;                       // dst aliases src
     if (h->comm) { NCCLCHECK(g_rccl.AllReduce(src, dst, count, ncclDouble, op ? ncclMax : ncclSum, h->comm, h->stream)); return TTX_OK; }
     if (!h->have_cb) return fail(TTX_ESTATE, "world_size > 1 but neither ttx_comm_init nor ttx_set_transport was called");
-    HIPCHECK(hipMemcpyAsync(h->h_tmp, src, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    if (h->cb.allreduce(h->cb.ctx, h->h_tmp, (int64_t)count, op)) return fail(TTX_EHIP, "transport allreduce failed");
-    HIPCHECK(hipMemcpyAsync(dst, h->h_tmp, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
+    // each pending reduction gets its own pinned slot and descriptor (several may be enqueued before the first one runs)
+    ttx_engine::RedJob *job = h->red_slot(count, op);
+    if (!job) return fail(TTX_EHIP, "allreduce staging exhausted");
+    HIPCHECK(hipMemcpyAsync(job->buf, src, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipLaunchHostFunc(h->stream, hostfn_allreduce, job));
+    HIPCHECK(hipMemcpyAsync(dst, job->buf, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
     return TTX_OK;
 }
 
@@ -719,17 +895,12 @@ static void print_line(const ttx_engine *h, const ttx_sweep_rec &r, double val_p
 static int readback(ttx_engine *h)
 {
     hipLaunchKernelGGL(k_collect, dim3(1), dim3(256), 0, h->stream, h->P);
-    if (h->W > 1 && !h->comm) {
-        // host-callback transport: reduce on the host copy directly
-        if (!h->have_cb) return fail(TTX_ESTATE, "world_size > 1 but neither ttx_comm_init nor ttx_set_transport was called");
-        HIPCHECK(hipMemcpyAsync(h->h_sum, h->P.sumsend, sizeof(double) * h->SB, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-        if (h->cb.allreduce(h->cb.ctx, h->h_sum, (int64_t)h->SB, 0)) return fail(TTX_EHIP, "transport allreduce failed");
-    } else {
+    {
         int rc = allreduce_dev(h, h->P.sumsend, h->P.sumrecv, h->SB, 0);
         if (rc) return rc;
         HIPCHECK(hipMemcpyAsync(h->h_sum, h->P.sumrecv, sizeof(double) * h->SB, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(hipStreamSynchronize(h->stream));
+        if (h->cb_error) return fail(TTX_EHIP, "host transport: a sendrecv / allreduce callback failed");
     }
     if (h->profile) ev_collect(h);
     return TTX_OK;
@@ -889,8 +1060,11 @@ static int run_impl(ttx_engine *h)
     // sweep it+1 is enqueued BEFORE the host has read the summary of sweep it -- the GPU never waits for the host.  When the rule fires, the one sweep that is already enqueued finds the stop flag and does nothing.
     // On a single GPU the per-sweep quadrature (only reported, never fed back) runs on its own stream next to the
     // following sweep: it reads a snapshot of the ranks and only slabs that already exist (appends are in place).
-    const bool pipe = (h->cluster || h->fused) && h->W == 1 && !h->profile;
-    const bool forkq = pipe && P.has_quad;
+    // With several processes the exchange and the summary travel by stream-ordered collectives (RCCL, or the host transport's
+    // host functions), so the same loop applies; only the fork of the quadrature is single-process (one communicator must
+    // not be driven from two streams at once).
+    const bool pipe = (h->cluster || h->fused) && !h->profile && !(getenv("TTX_PIPELINE") && atoi(getenv("TTX_PIPELINE")) == 0);
+    const bool forkq = pipe && P.has_quad && h->W == 1;
     DevProb Pq = P;
     if (pipe) Pq.r = P.rq;
 
@@ -948,8 +1122,13 @@ static int run_impl(ttx_engine *h)
             if (nproc > 1)
                 if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + 16 + sizeof(short) * 2 * (((d + 7) & ~7) + 8) + sizeof(double) * (64 * 64 + 4), st, Q); })) return rc_;
         }
-        if (pipe) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
-        if (pipe) HIPCHECK(hipEventRecord(h->ev_sum[slot], st));     // k_sweep_end wrote the summary into the pinned slot
+        if (pipe && h->W == 1) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
+        if (pipe && h->W > 1) {      // this GPU's part -> SUM all-reduce -> pinned slot, all stream-ordered
+            hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, P.sumsend);
+            if (int rc_ = allreduce_dev(h, P.sumsend, P.sumrecv, h->SB, 0)) return rc_;
+            HIPCHECK(hipMemcpyAsync(h->h_sum_base + (size_t)slot * h->SB, P.sumrecv, sizeof(double) * h->SB, hipMemcpyDeviceToHost, st));
+        }
+        if (pipe) HIPCHECK(hipEventRecord(h->ev_sum[slot], st));     // the summary of the sweep is in the pinned slot
         if (P.has_quad) {
             hipStream_t sq = forkq ? h->qstream : st;
             if (forkq) HIPCHECK(hipStreamWaitEvent(sq, h->ev_sum[slot], 0));    // fork point = end of the sweep's main-stream work
@@ -965,6 +1144,7 @@ static int run_impl(ttx_engine *h)
                 HIPCHECK(hipMemcpyAsync(h->h_val + slot, &P.gs[0].val, sizeof(double), hipMemcpyDeviceToHost, sq));
                 HIPCHECK(hipEventRecord(h->ev_val[slot], sq));
             }
+            if (h->cb_error) return fail(TTX_EHIP, "host transport: a sendrecv / allreduce callback failed");
         }
         return TTX_OK;
     };

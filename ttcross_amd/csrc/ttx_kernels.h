@@ -1829,7 +1829,10 @@ __global__ __launch_bounds__(256) void k_sweep_end(DevProb P, int it, double *ou
     for (int x = tid; x < n; x += blockDim.x) P.rq[x] = P.r[x];
     if (tid == 0) P.ctl[2] = P.ctl[0];
     if (P.ctl[0]) return;
-    for (int p = 1 + tid; p < m; p += blockDim.x) {          // owner of bond p, its rank and tape entry
+    // multi-GPU job: `out` is this GPU's contribution to a SUM all-reduce -- only the bonds of its own groups, and the
+    // job-wide scalars from the GPU that holds global group 0 (after k_exch_max_apply every GPU has the same maxima)
+    const int p_lo = P.gs[0].first, p_hi = P.gs[P.G - 1].last;
+    for (int p = p_lo + tid; p <= p_hi; p += blockDim.x) {   // owner of bond p, its rank and tape entry
         int g = 0;
         while (g + 1 < P.G && P.gs[g + 1].first <= p) g++;
         const int *r = P.r + (size_t)g * (m + 2), *tp = P.tape + (size_t)g * (m + 2) * 4;
@@ -1840,8 +1843,9 @@ __global__ __launch_bounds__(256) void k_sweep_end(DevProb P, int it, double *ou
     if (tid != 0) return;
     double nev = 0.0, by = 0.0, nr = 0.0;
     for (int g = 0; g < P.G; g++) { const GroupState &gs = P.gs[g]; nev += (double)gs.neval; by += gs.bytes_half; nr += (double)gs.n_resid; }
-    const double amax = P.gs[0].amax, pmax = P.gs[0].pivotmax;    // single GPU: local group 0 is global group 0
-    out[SUM_NEVAL] = nev; out[SUM_BYTES] = by; out[SUM_NRESID] = nr; out[SUM_AMAX] = amax; out[SUM_PMAX] = pmax; out[SUM_PMIN] = P.gs[0].pivotmin;
+    const double amax = P.gs[0].amax, pmax = P.gs[0].pivotmax;    // job-wide maxima (k_exch_max_apply), the same on every GPU
+    out[SUM_NEVAL] = nev; out[SUM_BYTES] = by; out[SUM_NRESID] = nr;
+    if (P.g0 == 0) { out[SUM_AMAX] = amax; out[SUM_PMAX] = pmax; out[SUM_PMIN] = P.gs[0].pivotmin; }
     out[SUM_VAL] = 0.0;
     int ready = (it + 1 >= P.maxrank);
     if (P.accuracy >= 0.0) {

@@ -265,6 +265,13 @@ class TTCross:
             buf[i] = ids[i]
         _check(L.ttx_comm_init(self._h, buf))
 
+    def comm_init_shm(self, name):
+        """The engine's built-in node-local transport over POSIX shared memory (include/ttx.h: ttx_comm_init_shm): every
+        rank of the job passes the same name.  No MPI, no RCCL, no torch.distributed."""
+        L = load_library()
+        L.ttx_comm_init_shm.argtypes = [c_void_p, ctypes.c_char_p]
+        _check(L.ttx_comm_init_shm(self._h, name.encode()))
+
     def set_dist_transport(self, dist, group=None):
         """Host-callback transport over torch.distributed CPU tensors (gloo): used where RCCL cannot run
         (several ranks on one GPU) -- same engine code path, messages staged through pinned host memory."""

@@ -11,7 +11,7 @@ module dmrgg_lib
  use time_lib
  use ttx_c
  implicit none
- private :: identify,ising_value,ttx_world,ttx_comm_init_file
+ private :: identify,ising_value,ttx_world,ttx_comm_init_file,ttx_comm_init_shm_env
 contains
  subroutine dtt_dmrgg(arg,fun,par,accuracy,maxrank,mybonds,pivoting,neval,quad,tru)
   type(dtt),intent(inout),target :: arg
@@ -85,7 +85,16 @@ contains
     call ttx_check(ttx_set_integrand_host(arg%ttx,c_funloc(fun),c_null_ptr),subnam)
    end if
   end if
-  if(wsize.gt.1)call ttx_check(ttx_comm_init_file(arg%ttx),subnam)
+  if(wsize.gt.1)then
+   ! transport between the processes: RCCL over xGMI (unique id through the file TTX_COMM_FILE), or with TTX_TRANSPORT=shm
+   ! the engine's node-local shared-memory transport (several ranks on one GPU, where RCCL cannot run)
+   call get_environment_variable('TTX_TRANSPORT',env,status=stat)
+   if(stat.eq.0 .and. trim(env).eq.'shm')then
+    call ttx_check(ttx_comm_init_shm_env(arg%ttx),subnam)
+   else
+    call ttx_check(ttx_comm_init_file(arg%ttx),subnam)
+   end if
+  end if
   call ttx_check(ttx_run(arg%ttx),subnam)
   ! results back into the caller's container: ranks and finalised cores (ownership as in the reference: each process
   ! holds the cores of its own groups; the others stay allocated at the global ranks)
@@ -264,6 +273,17 @@ contains
   if(stat.eq.0)read(env,*)wrank
   if(wsize.lt.1.or.wrank.lt.0.or.wrank.ge.wsize)then;write(*,*)'dtt_dmrgg: bad TTX_WORLD_RANK/TTX_WORLD_SIZE: ',wrank,wsize;stop;endif
  end subroutine
+ integer(c_int) function ttx_comm_init_shm_env(h) result(rc)
+  type(c_ptr),value :: h
+  character(len=256) :: nam
+  character(kind=c_char) :: cnam(257)
+  integer :: stat,i
+  call get_environment_variable('TTX_SHM_NAME',nam,status=stat)
+  if(stat.ne.0)nam='ttx_job'
+  do i=1,len_trim(nam); cnam(i)=nam(i:i); end do
+  cnam(len_trim(nam)+1)=c_null_char
+  rc=ttx_comm_init_shm(h,cnam)
+ end function
  integer(c_int) function ttx_comm_init_file(h) result(rc)
   ! RCCL bootstrap without MPI: rank 0 writes the 128-byte unique id to the file TTX_COMM_FILE (written under a temporary
   ! name and renamed, so readers never see a partial file); the other ranks wait for it.  With an MPI build of the

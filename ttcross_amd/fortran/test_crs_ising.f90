@@ -19,7 +19,7 @@ program main
  call readarg(1,a,'c'); call readarg(2,m,6); call readarg(3,n,65); call readarg(4,r,20); call readarg(5,piv,1)
  call mpi_init(info); call mpi_comm_size(MPI_COMM_WORLD,nproc,info); call mpi_comm_rank(MPI_COMM_WORLD,me,info)
  adj=0; if(mod(n,2).eq.0)then; n=n+1; adj=1; endif
- call banner()
+ if(me.eq.0)call banner()
  acc=500*epsilon(1.d0)
  allocate(par(2*n+1))
  select case(a)
@@ -45,8 +45,11 @@ program main
   call dtt_dmrgg(tt,dfunc_ising_discr,par,maxrank=r,accuracy=acc,pivoting=piv,neval=neval,quad=qq,tru=tru)
  endif
  t2=timef()
- write(*,'(a,i12,a,e12.4,a)') '...with',neval,' evaluations completed in ',t2-t1,' sec.'
- val=dtt_quad(tt,qq)
+ if(me.eq.0)write(*,'(a,i12,a,e12.4,a)') '...with',neval,' evaluations completed in ',t2-t1,' sec.'
+ val=dtt_quad(tt,qq)                          ! collective: every process takes part, the report is rank 0's (test_crs_ising.f90:158-169)
+ if(me.ne.0)then
+  call dealloc(tt); call mpi_finalize(info); stop
+ end if
  if(rescale)then
   write(*,'(a,e50.40,a,i4,a)') 'computed value:',val,' / (5**',m-1,')'
  else

@@ -48,6 +48,9 @@ module ttx_c
   function ttx_comm_init(h,id) bind(C,name='ttx_comm_init') result(rc)
    import; type(c_ptr),value :: h; integer(c_int8_t) :: id(128); integer(c_int) :: rc
   end function
+  function ttx_comm_init_shm(h,name) bind(C,name='ttx_comm_init_shm') result(rc)   ! node-local host transport (several ranks on one GPU, no MPI)
+   import; type(c_ptr),value :: h; character(kind=c_char) :: name(*); integer(c_int) :: rc
+  end function
   function ttx_run(h) bind(C,name='ttx_run') result(rc)
    import; type(c_ptr),value :: h; integer(c_int) :: rc
   end function
