@@ -188,6 +188,30 @@ def test_config4_mvn_128_full_size_vs_reference_log():
     assert abs(tt.quad(s["quad"]) - g_val) <= 0.05 * abs(g_val)
 
 
+FULLPIV = [("c", 5, 9, 6), ("d", 4, 11, 5), ("c", 8, 17, 10), ("e", 6, 9, 8)]
+
+
+@pytest.mark.parametrize("kind,m,n,r", FULLPIV, ids=[f"{c[0]}{c[1]}_n{c[2]}_r{c[3]}" for c in FULLPIV])
+def test_full_pivoting_dense_mfma_by_tolerance(monkeypatch, kind, m, n, r):
+    """pivoting = -1 as one dense step (TTX_FULLPIV=mfma, lib/dmrgg.f90:341-408): the superblock evaluated once, the
+    residual A - col x row by an fp64 MFMA GEMM fused with the arg-max.  The matrix cores accumulate in their own order, so
+    the residuals differ from the reference's dgemm in the last bits: parity BY TOLERANCE against the oracle -- the same
+    number of sweeps, ranks and evaluations, every per-sweep value to 1e-9 relative, the integral to 1e-11 -- and against
+    the engine's own column-by-column path, which stays bit-identical to the oracle (test_ising_sweep_bit_exact)."""
+    s = D.ising_setup(kind, m, n)
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=-1, accuracy=s["acc"], quad=s["quad"], tru=s["tru"])
+    monkeypatch.setenv("TTX_FULLPIV", "mfma")
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=-1, accuracy=s["acc"], quad=s["quad"], tru=s["tru"]).run()
+    gs, os_ = tt.sweeps(), oo["sweeps"]
+    assert len(gs) == len(os_)
+    for a, b in zip(gs, os_):
+        assert a["neval"] == b["neval"] and a["erank"] == b["erank"]
+        assert abs(a["val"] - b["val"]) <= 1e-9 * abs(b["val"]), f"sweep {a['it']}"
+        assert a["amax"] == b["amax"]
+    assert np.array_equal(tt.ranks(), oo["r"])
+    assert abs(tt.quad(s["quad"]) - oo["value"]) <= 1e-11 * abs(oo["value"])
+
+
 def test_k2_residual_argmax_bit_exact():
     rng = np.random.default_rng(1)
     for m, r in [(1632, 32), (6464, 64), (33, 1), (700, 17), (51, 0)]:

@@ -20,6 +20,44 @@
 #pragma once
 #include "ttx_kernels.h"
 
+// a = (..((a * p[0]) * p[1]) ..) * p[len-1] for an LDS row read with a wave-uniform address (broadcasts).  A lone wave
+// has nobody to hide the LDS latency behind, so the loop is software-pipelined by hand: the reads of the NEXT eight
+// factors are issued before the eight dependent multiplies of the current ones.
+__device__ __forceinline__ double lds_chain(double a, const double *p, int len)
+{
+    int c = 0;
+    if (len >= 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = p[q];
+        c = 8;
+        for (;;) {                                   // two stages per trip, so that no register copies are needed
+            if (c + 8 > len) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) a = a * x[q];
+                break;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) y[q] = p[c + q];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a = a * x[q];
+            c += 8;
+            if (c + 8 > len) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) a = a * y[q];
+                break;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) x[q] = p[c + q];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a = a * y[q];
+            c += 8;
+        }
+    }
+    for (; c < len; c++) a = a * p[c];
+    return a;
+}
+
 // wave-uniform stream of doubles g[0..total) consumed in order by all lanes of ONE wave
 struct WStream {
     const double *g; double *buf; double rA, rB; int total, nextb, avail, rd;
@@ -38,16 +76,7 @@ struct WStream {
         while (cnt > 0) {
             if (avail == 0) refill(lane);
             const int mm = cnt < avail ? cnt : avail;
-            const double *p = buf + rd;
-            int k = 0;
-            for (; k + 8 <= mm; k += 8) {
-                double x[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) x[q] = p[k + q];
-#pragma unroll
-                for (int q = 0; q < 8; q++) a = a * x[q];
-            }
-            for (; k < mm; k++) a = a * p[k];
+            a = lds_chain(a, buf + rd, mm);
             rd += mm; avail -= mm; cnt -= mm;
         }
         return a;
@@ -60,11 +89,16 @@ __device__ __forceinline__ void de_run(double &a, double u, double x2, const dou
 {
     u = u * x2; a = a * de_t2<FAST>(u);
     int j = 0;
-    for (; j + 4 <= B; j += 4) {                       // four independent divisions in flight; products in order
-        const double u1 = u * xr[j], u2 = u1 * xr[j + 1], u3 = u2 * xr[j + 2], u4 = u3 * xr[j + 3];
-        const double t1 = de_t2<FAST>(u1), t2 = de_t2<FAST>(u2), t3 = de_t2<FAST>(u3), t4 = de_t2<FAST>(u4);
-        a = a * t1; a = a * t2; a = a * t3; a = a * t4;
-        u = u4;
+    if (B >= 4) {
+        double y0 = xr[0], y1 = xr[1], y2 = xr[2], y3 = xr[3];
+        for (; j + 4 <= B; j += 4) {                   // four independent divisions in flight; products in order
+            const double x0 = y0, x1_ = y1, x2_ = y2, x3 = y3;
+            if (j + 8 <= B) { y0 = xr[j + 4]; y1 = xr[j + 5]; y2 = xr[j + 6]; y3 = xr[j + 7]; }    // next batch's LDS reads fly under the divisions
+            const double u1 = u * x0, u2 = u1 * x1_, u3 = u2 * x2_, u4 = u3 * x3;
+            const double t1 = de_t2<FAST>(u1), t2 = de_t2<FAST>(u2), t3 = de_t2<FAST>(u3), t4 = de_t2<FAST>(u4);
+            a = a * t1; a = a * t2; a = a * t3; a = a * t4;
+            u = u4;
+        }
     }
     for (; j < B; j++) { u = u * xr[j]; a = a * de_t2<FAST>(u); }
 }
@@ -181,4 +215,128 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
         wave_argmax(ab, bb, bi);
         if (lane == 0) { Partial pr; pr.absmax = ab; pr.val = bb; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][w] = pr; }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One element per WAVE (lottery candidates, boundary corners): the chip holds few of these evaluations at a time, and a
+// lone lane needs ~32 640 x 20 cycles for one.  Here the 64 lanes share ONE element, so every operand is wave-uniform:
+//   * division phase: lane r of a tile owns ROW i0+r of the pair triangle (rows are independent: each has its own
+//     running product u) and writes its factors ((u-1)/(u+1))^2 to an LDS tile T2[r][.] -- RT rows per tile;
+//   * product phase: all lanes multiply the tile's factors into `a` in the reference's order (row by row, LDS
+//     broadcasts), with the tabulated factors of the pivots streamed in between (WStream) when tables exist.
+// The value of `a` -- and everything after it -- is computed redundantly and identically by all lanes.
+// ------------------------------------------------------------------------------------------------------------------
+#define DE_RT 16                 // rows of pair factors per LDS tile
+__host__ __device__ inline size_t de_wave_lds_doubles(int m) { const int VS = ((m + 7) & ~7) + 8; return (size_t)3 * VS + 128 + (size_t)DE_RT * (VS + 1); }
+
+// b-part (id 2) and weights (test_crs_ising.f90:197-218) from per-dimension value arrays xv / wv (0-based dims)
+__device__ __forceinline__ double de_finish_vals(int id, double a, int m, const double *xv, const double *wv)
+{
+    double b = 0.0;
+    if (id == 2) {
+        double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
+        for (int j = m - 1; j >= 0; j--) { vk = vk * xv[j]; v = v + vk; }
+        for (int j = 0; j < m; j++) { wk = wk * xv[j]; w = w + wk; }
+        b = 1.0 / (v * w);
+    }
+    double f = (id == 2) ? 2 * a * b : 2 * a;
+    for (int j = 0; j < m; j++) f = f * wv[j];
+    return f;
+}
+
+__device__ __forceinline__ double de_row_chain(double a, const double *row, int len) { return lds_chain(a, row, len); }
+
+// pair product of ONE element without tables: every pair (i, j), 0 <= i < j <= m, by division.  xv[0..m) in LDS.
+template <bool FAST>
+__device__ __forceinline__ double de_elem_full(int m, const double *xv, double *T2, int lane)
+{
+    const int RS = ((m + 7) & ~7) + 9;                 // odd row stride in doubles: 16 rows hit 16 different bank pairs
+    double a = 1.0;
+    for (int i0 = 0; i0 < m; i0 += DE_RT) {
+        const int nr = min(DE_RT, m - i0), maxlen = m - i0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nr) {
+            const int i = i0 + lane, len = m - i;      // row i: pairs (i, i+1..m), factors of dims i+1..m = xv[i..m)
+            double u = 1.0;
+            double *row = T2 + (size_t)lane * RS;
+            for (int c = 0; c < maxlen; c++) {
+                if (c < len) { u = u * xv[i + c]; row[c] = de_t2<FAST>(u); }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < nr; r++) a = de_row_chain(a, T2 + (size_t)r * RS, m - (i0 + r));
+    }
+    return a;
+}
+
+// the same with the pivots' tables: rows 0..A+1 carry only the bond-spanning pairs (B+2 per row; row A+1 starts after
+// dim p, its first slot holds the neutral 1.0), TL factors are streamed before each row, TR factors after the last
+template <bool FAST>
+__device__ __forceinline__ double de_elem_tab(int m, int A, const double *xv, const double *UL, WStream &sl, WStream &sr, double *T2, int lane)
+{
+    const int RS = ((m + 7) & ~7) + 9;
+    const int B = m - A - 2, nrow = A + 2, len = B + 2;
+    const double x1 = xv[A], x2 = xv[A + 1];
+    const double *xr = xv + A + 2;
+    double a = 1.0;
+    for (int i0 = 0; i0 < nrow; i0 += DE_RT) {
+        const int nr = min(DE_RT, nrow - i0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nr) {
+            const int i = i0 + lane;
+            double *row = T2 + (size_t)lane * RS;
+            double u = 1.0;
+            if (i <= A) { u = UL[i] * x1; row[0] = de_t2<FAST>(u); } else row[0] = 1.0;
+            u = u * x2; row[1] = de_t2<FAST>(u);
+            int j = 0;
+            for (; j + 4 <= B; j += 4) {
+                const double u1 = u * xr[j], u2 = u1 * xr[j + 1], u3 = u2 * xr[j + 2], u4 = u3 * xr[j + 3];
+                row[2 + j] = de_t2<FAST>(u1); row[3 + j] = de_t2<FAST>(u2); row[4 + j] = de_t2<FAST>(u3); row[5 + j] = de_t2<FAST>(u4);
+                u = u4;
+            }
+            for (; j < B; j++) { u = u * xr[j]; row[2 + j] = de_t2<FAST>(u); }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < nr; r++) {
+            const int i = i0 + r;
+            if (i <= A) a = sl.chain(a, A - i, lane);
+            a = de_row_chain(a, T2 + (size_t)r * RS, len);
+        }
+    }
+    return sr.chain(a, B * (B + 1) / 2, lane);
+}
+
+// lottery candidates (lib/dmrgg.f90:455-463) of the Ising D / E integrands: one candidate per wave.  grid = (nlot, groups).
+// The candidates were drawn by k_lottery (phase 1) into P.lotc; values go to P.lotf for k_lottery (phase 2).
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_lottery_eval_de(DevProb P)
+{
+    extern __shared__ __align__(16) double dyn[];
+    const int g = blockIdx.y, il = blockIdx.x, lane = threadIdx.x, m = P.d;
+    const GroupState &gs = P.gs[g];
+    const StepState &st = gs.S[0];
+    if (!st.active) return;
+    const int p = st.p, first = gs.first;
+    const int nlot = st.r0 + st.n1 + st.n2 + st.r2;
+    if (il >= nlot) return;
+    const int *cand = P.lotc + ((size_t)g * P.lot_max + il) * 4;
+    const int ci = cand[0] - 1, cj = cand[1] - 1, ck = cand[2] - 1, cq = cand[3] - 1;
+    const int A = p - 1, B = m - p - 1, VS = ((m + 7) & ~7) + 8, n1m = P.n[1];
+    double *xv = dyn, *wv = xv + VS, *UL = wv + VS, *ringL = UL + VS, *ringR = ringL + 64, *T2 = ringR + 64;
+    const double *nodes = P.par, *weights = P.par + n1m;
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    for (int x = lane; x < m; x += 64) {
+        const int ix = (x < A) ? Lt[(size_t)x * P.RM + ci] - 1 : (x == A) ? cj : (x == A + 1) ? ck : Rt[(size_t)(x - A - 2) * P.RM + cq] - 1;
+        xv[x] = nodes[ix]; wv[x] = weights[ix];
+    }
+    const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
+    const double *ULg = P.deUL + ((size_t)g * P.RM + ci) * (m + 1);
+    for (int x = lane; x <= A; x += 64) UL[x] = ULg[x];
+    WStream sl, sr;
+    sl.init(P.deTL + (size_t)g * tsz + (size_t)ci * NP, A * (A + 1) / 2, ringL, lane);
+    sr.init(P.deTR + (size_t)g * tsz + (size_t)cq * NP, B * (B + 1) / 2, ringR, lane);
+    __syncthreads();
+    const double a = de_elem_tab<FAST>(m, A, xv, UL, sl, sr, T2, lane);
+    const double f = de_finish_vals(P.ising_id, a, m, xv, wv);
+    if (lane == 0) P.lotf[(size_t)g * P.lot_max + il] = f;
 }

@@ -116,6 +116,10 @@ struct DevProb {
     double *sumsend, *sumrecv;     // per-sweep job summary (SUM all-reduce): see SUM_* offsets
     int g0;                        // global index of local group 0
     Partial *pfull;                // [G][NM*RM*nfb] partial arg-max records of the full-superblock search (piv = -1)
+    // piv = -1 as ONE dense step (TTX_FULLPIV=mfma): the superblock is evaluated once into sb [G][(RM*NM)^2], its residual
+    // against col(p) x row(p+1) is taken by an fp64 MFMA GEMM fused with the arg-max (k_full_gemm_argmax), one partial
+    // record per 64x64 tile in pfull2 [G][fp_tiles]
+    double *sb; Partial *pfull2; int fp_mfma, fp_tiles;
     int nfb;                       // fiber blocks per half-step launch
     const ttx_cdfseg *cdf_tab;     // [cdf_kmax+1][TTX_TABSEG] lottery CDF segments for every K (nullptr: build in-kernel)
     const int *cdf_ns;             // [cdf_kmax+1]
@@ -132,6 +136,9 @@ struct DevProb {
     struct LotPart *lotp;
     unsigned *lot_ctr;
     int lot_nb;
+    // Ising D/E lottery in three launches (pick / one candidate per wave / fold): candidates [G][lot_max][4], values [G][lot_max]
+    int *lotc; double *lotf; int lot_max;
+    int bnd_wave;                  // boundary corner entries of Ising D/E by one wave each (k_exch_boundary has the LDS for it)
     // host-evaluated integrand (TTX_FUN_HOST, the reference's user callback `fun`, lib/dmrgg.f90:18): every kernel that
     // evaluates runs twice.  Pass 1 (hostpass = 1) writes the multi-index of each point it needs to hidx[slot][d], raises
     // hreq[slot] and stops before any side effect; the host calls `fun`; pass 2 (hostpass = 2) reads hval[slot].

@@ -135,6 +135,7 @@ struct ttx_engine {
     int half_vals = 0, lot_vals = 0;
     int de_v2 = 0;                      // Ising D/E: wave-per-pivot half-step kernel k_halfstep_de (ttx_de.h)
     int de_slots = 0; size_t lds_de = 0;
+    int lot_wave = 0; size_t lds_dew = 0;   // Ising D/E: lottery candidates and boundary corners one element per wave (ttx_de.h)
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
     hipStream_t qstream = nullptr;      // forked per-sweep quadrature (single-process runs)
@@ -403,6 +404,14 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     }
     P.nfb = (int)((RM * NM + TTX_BLK - 1) / TTX_BLK);
     if (cfg->pivoting < 0) A_(dev_alloc(h, &P.pfull, G * NM * RM * (size_t)P.nfb));
+    if (cfg->pivoting < 0 && getenv("TTX_FULLPIV") && std::string(getenv("TTX_FULLPIV")) == "mfma" && RM <= 64 &&
+        (long long)(RM * NM) * (long long)(RM * NM) < (1LL << 31)) {
+        // dense full pivoting: the whole superblock resident (8 (RM NM)^2 bytes per group: 21 MB at r=32, n=51; 334 MB at r=64, n=101)
+        const size_t side = RM * NM, tiles = ((side + 63) / 64) * ((side + 63) / 64);
+        A_(dev_alloc(h, &P.sb, G * side * side));
+        A_(dev_alloc(h, &P.pfull2, G * tiles));
+        P.fp_mfma = 1; P.fp_tiles = (int)tiles;
+    }
     // exchange buffers
     P.XD = RM * NM + RM * RM;
     P.IOFF = (sizeof(int) * (XH + d + 2) + 15) & ~(size_t)15;
@@ -550,6 +559,16 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         rc = dev_alloc(h, &lp, (size_t)h->G * P.lot_nb); if (rc) { ttx_destroy(h); return rc; }
         rc = dev_alloc(h, &lc, (size_t)h->G); if (rc) { ttx_destroy(h); return rc; }
         P.lotp = lp; P.lot_ctr = lc;
+        P.lot_max = nlotmax;
+        if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && P.deTL) {
+            int *lcd; double *lf;
+            rc = dev_alloc(h, &lcd, (size_t)h->G * nlotmax * 4); if (rc) { ttx_destroy(h); return rc; }
+            rc = dev_alloc(h, &lf, (size_t)h->G * nlotmax); if (rc) { ttx_destroy(h); return rc; }
+            P.lotc = lcd; P.lotf = lf;
+            h->lds_dew = sizeof(double) * de_wave_lds_doubles(d);
+            h->lot_wave = h->de_v2 && h->lds_dew <= 150 * 1024 && !(getenv("TTX_LOTTERY_WAVE") && atoi(getenv("TTX_LOTTERY_WAVE")) == 0);
+            P.bnd_wave = h->lot_wave;
+        }
     }
     if (cfg->fun_id == TTX_FUN_HOST) {
         // slots of one group: the largest point set any evaluating kernel asks for in one launch
@@ -993,6 +1012,9 @@ static int run_impl(ttx_engine *h)
         static size_t a_de0 = 0, a_de1 = 0;
         if (h->de_v2 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<true>), h->lds_de, a_de0)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<false>), h->lds_de, a_de1)))) return rc;
+        static size_t a_lw0 = 0, a_lw1 = 0;
+        if (h->lot_wave && ((rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de<true>), h->lds_dew, a_lw0)) ||
+                            (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de<false>), h->lds_dew, a_lw1)))) return rc;
     }
     if (h->cluster) *h->h_abort = 0;
     // an evaluating kernel: once with the device integrand; with a host integrand twice around the host's calls
@@ -1085,7 +1107,14 @@ static int run_impl(ttx_engine *h)
                 hipLaunchKernelGGL(k_de_tables, dim3((2 * (d + 1) * h->RM + 255) / 256, G), dim3(256), 0, st, P, dir, pp);
             }
             if (h->cfg.pivoting >= 0) {
-                { KScope ks(h, TTX_K_LOTTERY); if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_lottery<FUN>, dim3(P.lot_nb, G), dim3(P.lot_nb == 1 ? 512 : 256), h->lds_lot, st, Q, dir, pp, h->lot_vals); })) return rc_; }
+                if (FUN == FUN_ISING && h->lot_wave) {
+                    KScope ks(h, TTX_K_LOTTERY, 3);
+                    hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 1);
+                    if (P.de_unit) hipLaunchKernelGGL(k_lottery_eval_de<true>, dim3(P.lot_max, G), dim3(64), h->lds_dew, st, P);
+                    else hipLaunchKernelGGL(k_lottery_eval_de<false>, dim3(P.lot_max, G), dim3(64), h->lds_dew, st, P);
+                    hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 2);
+                } else
+                { KScope ks(h, TTX_K_LOTTERY); if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_lottery<FUN>, dim3(P.lot_nb, G), dim3(P.lot_nb == 1 ? 512 : 256), h->lds_lot, st, Q, dir, pp, h->lot_vals, 0); })) return rc_; }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
                 if (FUN == FUN_ISING && h->de_v2) {
                     for (int hh = 0; hh < h->H; hh++) {
@@ -1100,8 +1129,16 @@ static int run_impl(ttx_engine *h)
                 // then the cross through the winner (evaluation only)
                 KScope ks(h, TTX_K_HALFSTEP, 5);
                 hipLaunchKernelGGL(k_bond_begin, dim3(G), dim3(64), 0, st, P, dir, pp);
+                if (P.fp_mfma && FUN != FUN_HOST) {
+                    // one dense step: evaluate the superblock once, residual by fp64 MFMA fused with the arg-max
+                    const int side = h->RM * h->NM, gx = (side + 63) / 64;
+                    hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 4, h->half_vals);
+                    hipLaunchKernelGGL(k_full_gemm_argmax, dim3(gx, gx, G), dim3(256), 0, st, P);
+                    hipLaunchKernelGGL(k_full_resolve2, dim3(G), dim3(256), 0, st, P, gx, gx);
+                } else {
                 hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 3, h->half_vals);
                 hipLaunchKernelGGL(k_full_resolve, dim3(G), dim3(256), 0, st, P);
+                }
                 hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 2, h->half_vals);
                 hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 1, dir, 2, h->half_vals);
             }
@@ -1119,8 +1156,14 @@ static int run_impl(ttx_engine *h)
                 if (int rc_ = allreduce_dev(h, P.redsend, P.redrecv, 4, 1)) return rc_;
             }
             hipLaunchKernelGGL(k_exch_max_apply, dim3(G), dim3(256), 0, st, P, h->W > 1 ? 1 : 0, nproc > 1 ? 1 : 0);
-            if (nproc > 1)
-                if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), h->lds_par + 16 + sizeof(short) * 2 * (((d + 7) & ~7) + 8) + sizeof(double) * (64 * 64 + 4), st, Q); })) return rc_;
+            if (nproc > 1) {
+                const size_t VSb = ((d + 7) & ~7) + 8;
+                const size_t lds_b = h->lds_par + 16 + sizeof(short) * 2 * VSb + sizeof(double) * (64 * 64 + 4) +
+                                     (P.bnd_wave ? sizeof(double) * (2 * VSb + (size_t)DE_RT * (VSb + 1) + 8) : 0);
+                static size_t a_bnd = 0;
+                if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_exch_boundary<FUN>), lds_b, a_bnd)) return rc_;
+                if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), lds_b, st, Q); })) return rc_;
+            }
         }
         if (pipe && h->W == 1) hipLaunchKernelGGL(k_sweep_end, dim3(1), dim3(256), 0, st, P, it_, h->h_sum_base + (size_t)slot * h->SB);
         if (pipe && h->W > 1) {      // this GPU's part -> SUM all-reduce -> pinned slot, all stream-ordered

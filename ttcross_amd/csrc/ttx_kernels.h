@@ -805,6 +805,91 @@ __global__ __launch_bounds__(256) void k_full_resolve(DevProb P)
     }
 }
 
+// piv = -1 as one dense step (lib/dmrgg.f90:384-396): B = A - col(p) * row(p+1) over the whole superblock by fp64 MFMA
+// (v_mfma_f64_16x16x4_f64; operand lane maps as k_gemm_mfma in ttx_ttops.h) fused with the arg-max of |B|.
+// A = sb [(i,j) fastest, nf = r0*n1 rows][(k,q), nc = n2*r2 columns]; col(p)[(i + RM j) + SS s]; row(p+1)[(k + NM q) + SW s].
+// grid = (ceil(nf/64), ceil(nc/64), groups), 256 threads: wave w owns rows 16w..16w+15 of the 64x64 tile, the row-factor
+// tile (K x 64) is staged in LDS once per block.  The MFMA accumulates in its own order, so the residuals differ from the
+// reference's dgemm in the last bits: this path is checked by tolerance, the column-by-column path (mode 3) stays the
+// bit-exact checker.  One Partial per tile, first-max rule on the superblock's linear index t + nf * column.
+typedef double dbl4_ __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_full_gemm_argmax(DevProb P)
+{
+    __shared__ double Bt[64 * 65];                     // row factor tile: Bt[k * 65 + c], K <= 64
+    __shared__ double sha[4], shv[4]; __shared__ int shi[4];
+    const int g = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const GroupState &gs = P.gs[g];
+    const StepState &st = gs.S[0];
+    if (!st.active) return;
+    const int p = st.p, r0 = st.r0, r1 = st.r1, r2 = st.r2, n1 = st.n1, n2 = st.n2, first = gs.first;
+    const int nf = r0 * n1, nc = n2 * r2;
+    const int tm = blockIdx.x * 64, tn = blockIdx.y * 64;
+    if (tm >= nf || tn >= nc) return;
+    const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+    const double *sb = P.sb + (size_t)g * ((size_t)P.RM * P.NM) * ((size_t)P.RM * P.NM);
+    for (int x = tid; x < r1 * 64; x += 256) {
+        const int k = x >> 6, c = x & 63, col = tn + c;
+        double v = 0.0;
+        if (col < nc) { const int kk = col % n2, qq = col / n2; v = Wq[kk + (size_t)P.NM * qq + P.SW * k]; }
+        Bt[k * 65 + c] = v;
+    }
+    __syncthreads();
+    const int ar = tm + 16 * wave + (l & 15), kq = l >> 4;
+    const bool arok = ar < nf;
+    const size_t aoff = arok ? (size_t)(ar % r0) + (size_t)P.RM * (ar / r0) : 0;
+    dbl4_ acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) acc[nt] = dbl4_{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < r1; k0 += 4) {
+        const int k = k0 + kq;
+        const double a = (arok && k < r1) ? Cp[aoff + P.SS * k] : 0.0;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const double b = (k < r1) ? Bt[k * 65 + 16 * nt + (l & 15)] : 0.0;
+            acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[nt], 0, 0, 0);
+        }
+    }
+    double ab = -1.0, bv = 0.0; int bi = INT_MAX;
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = tm + 16 * wave + (l >> 4) + 4 * reg, col = tn + 16 * nt + (l & 15);
+            if (row < nf && col < nc) {
+                const size_t ix = (size_t)row + (size_t)nf * col;
+                const double b = sb[ix] - acc[nt][reg];
+                const double a_ = fabs(b);
+                if (a_ > ab || (a_ == ab && (int)ix < bi)) { ab = a_; bv = b; bi = (int)ix; }
+            }
+        }
+    block_argmax(ab, bv, bi, sha, shv, shi);
+    if (tid == 0) { Partial pr; pr.absmax = ab; pr.val = bv; pr.idx = bi; pr.pad = 0; P.pfull2[(size_t)g * P.fp_tiles + blockIdx.y * gridDim.x + blockIdx.x] = pr; }
+}
+__global__ __launch_bounds__(256) void k_full_resolve2(DevProb P, int gx, int gy)
+{
+    __shared__ double sha[4], shv[4]; __shared__ int shi[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    GroupState &gs = P.gs[g];
+    StepState st = gs.S[0];
+    if (!st.active) return;
+    const int nf = st.r0 * st.n1, nc = st.n2 * st.r2;
+    const int ux = (nf + 63) / 64, uy = (nc + 63) / 64;          // tiles that hold data
+    double ba = -1.0, bv = 0.0; int bi = INT_MAX;
+    for (int x = tid; x < ux * uy; x += blockDim.x) {
+        const Partial pr = P.pfull2[(size_t)g * P.fp_tiles + (x / ux) * gx + (x % ux)];
+        if (pr.absmax > ba || (pr.absmax == ba && pr.idx < bi)) { ba = pr.absmax; bv = pr.val; bi = pr.idx; }
+    }
+    block_argmax(ba, bv, bi, sha, shv, shi);
+    if (tid == 0) {                                       // :388-396
+        int x = bi;
+        st.qq = x / (nf * st.n2) + 1; x %= nf * st.n2;
+        st.kk = x / nf + 1; x %= nf;
+        st.jj = x / st.r0 + 1; st.ii = x % st.r0 + 1;
+        st.pivot = bv;
+        gs.S[0] = st;
+    }
+}
+
 // Ising D / E: per-bond tables of the pair factors that do not span the bond (see de_pairs_tab).  For every left
 // pivot c of bond p-1 (dims 1..A, A = p-1) and every start i: TL[c*NP + off(i) + j-i-1] = ((u-1)/(u+1))^2 with
 // u = x_{i+1}*...*x_j accumulated left to right (test_crs_ising.f90:188-192), UL[c*(m+1) + i] = u after j = A; the
@@ -855,7 +940,7 @@ __global__ __launch_bounds__(256) void k_de_tables(DevProb P, int dir, int pp)
 // one block per group
 // ------------------------------------------------------------------------------------------------
 template <int FUN>
-__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int vals)
+__global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int vals, int phase)
 {
     extern __shared__ __align__(16) double dyn[];
     __shared__ StepState st;
@@ -868,9 +953,11 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     const int nbl = (int)gridDim.x, blk = (int)blockIdx.x;
     GroupState &gs = P.gs[g];
     STAMP_DECL;
-    if (tid == 0) bond_state(P, g, dir, pp, st);
+    // phase 0: everything in this launch.  Ising D/E (one candidate per wave, ttx_de.h): phase 1 draws the candidates into
+    // P.lotc and leaves the state in gs.S[0]; k_lottery_eval_de fills P.lotf; phase 2 takes residuals, arg-max and state.
+    if (tid == 0) { if (phase == 2) st = gs.S[0]; else bond_state(P, g, dir, pp, st); }
     __syncthreads();
-    if (!st.active) { if (tid == 0) gs.S[0] = st; return; }
+    if (!st.active) { if (tid == 0 && phase != 2) gs.S[0] = st; return; }
     STAMP(gs, 0);   // 0: state
     const int p = st.p, r0 = st.r0, r1 = st.r1, r2 = st.r2, n1 = st.n1, n2 = st.n2, first = gs.first;
     const int nlot = r0 + n1 + n2 + r2;
@@ -887,7 +974,9 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     // mvn: rows of differences x - mu (doubles) take the place of the index rows (host sized the LDS for them: vals)
     const bool usem = (FUN == FUN_MVN) && (vals != 0);
     double *DLv = (double *)(((size_t)LT + 15) & ~(size_t)15), *DRv = DLv + (size_t)r0 * VS;
-    if (usem) {
+    if (phase != 0) {
+        // no evaluation in this launch: the pivot rows are not needed
+    } else if (usem) {
         __syncthreads();
         const double *mu = P.aux;
         for (int x = tid; x < r0 * VS; x += blockDim.x) { const int c = x / VS, o = x - c * VS; DLv[x] = (o < p - 1) ? par[Lt[(size_t)o * P.RM + c] - 1] - mu[o] : 0.0; }
@@ -900,11 +989,14 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     // generator word 48271^(2k+1): split as [48271^(2 pos+1)] * [48271^2]^il so that the long jump-ahead is done
     // once per block (threads 32/33) while every thread raises the short power
     __shared__ unsigned long long sA[2];
-    if (tid == 32) sA[0] = ttx_minstd_pow(2 * gs.rngpos + 1);
-    if (tid == 33) sA[1] = ttx_minstd_pow(2 * (gs.rngpos + nlot) + 1);
+    int Kc = 0, Kr = 0;
     const int CH = (nbl == 1) ? nlot : 64;                     // candidates per block
     const int il_first = blk * CH + tid, il_end = min(nlot, (blk + 1) * CH);
-    unsigned long long bil = ttx_minstd_pow(2ull * (unsigned long long)il_first);
+    unsigned long long bil = 0;
+    if (phase != 2) {
+    if (tid == 32) sA[0] = ttx_minstd_pow(2 * gs.rngpos + 1);
+    if (tid == 33) sA[1] = ttx_minstd_pow(2 * (gs.rngpos + nlot) + 1);
+    bil = ttx_minstd_pow(2ull * (unsigned long long)il_first);
     // zero-weight positions (existing pivots), :432-439
     const int *vp = vip_ptr(P, g, p, first);
     if (tid < r1) {
@@ -932,7 +1024,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     }
     __syncthreads();
     STAMP(gs, 0);   // 1: tables + powers + zero lists
-    const int Kc = r0 * n1 - nzc, Kr = n2 * r2 - nzr;
+    Kc = r0 * n1 - nzc; Kr = n2 * r2 - nzr;
     if (P.cdf_tab && Kc <= P.cdf_kmax && Kr <= P.cdf_kmax) {
         // segment tables depend on K only: precomputed at ttx_create, copied here
         if (tid < 64) { if (tid < P.cdf_ns[Kc]) segc[tid] = P.cdf_tab[(size_t)Kc * TTX_TABSEG + tid]; if (tid == 0) nsc = P.cdf_ns[Kc]; }
@@ -941,20 +1033,29 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         if (tid == 0) nsc = ttx_cdf_build(Kc, segc);
         if (tid == 64) nsr = ttx_cdf_build(Kr, segr);
     }
+    }
     __syncthreads();
     STAMP(gs, 0);   // 2: cdf
     double ma = 0.0;
     double ba = -1.0, bv = 0.0; int bi = INT_MAX;
     for (int il = il_first; il < il_end; il += blockDim.x) {
-        double d1, d2;
-        if (il == il_first) { d1 = ttx_flang_from_word(ttx_mulmod31(sA[0], bil)); d2 = ttx_flang_from_word(ttx_mulmod31(sA[1], bil)); }
-        else { d1 = ttx_flang_draw(gs.rngpos + il); d2 = ttx_flang_draw(gs.rngpos + nlot + il); }
-        const int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);      // rnd.f90:122-123
-        const int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
-        const int i = (x - 1) % r0 + 1, j = (x - 1) / r0 + 1, k = (y - 1) % n2 + 1, q = (y - 1) / n2 + 1;   // :447-452
+        int i, j, k, q;
+        if (phase != 2) {
+            double d1, d2;
+            if (il == il_first) { d1 = ttx_flang_from_word(ttx_mulmod31(sA[0], bil)); d2 = ttx_flang_from_word(ttx_mulmod31(sA[1], bil)); }
+            else { d1 = ttx_flang_draw(gs.rngpos + il); d2 = ttx_flang_draw(gs.rngpos + nlot + il); }
+            const int x = ttx_lottery_index(segc, nsc, Kc, r0 * n1, zc, nzc, d1);      // rnd.f90:122-123
+            const int y = ttx_lottery_index(segr, nsr, Kr, n2 * r2, zr, nzr, d2);
+            i = (x - 1) % r0 + 1; j = (x - 1) / r0 + 1; k = (y - 1) % n2 + 1; q = (y - 1) / n2 + 1;   // :447-452
+            if (phase == 1) { int *c_ = P.lotc + ((size_t)g * P.lot_max + il) * 4; c_[0] = i; c_[1] = j; c_[2] = k; c_[3] = q; continue; }
+        } else {
+            const int *c_ = P.lotc + ((size_t)g * P.lot_max + il) * 4;
+            i = c_[0]; j = c_[1]; k = c_[2]; q = c_[3];
+        }
         lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
         double f;
-        if (usem) f = f_mvn_rows<2>(m, P.auxT, P.mvn_norm, DLv + (size_t)(i - 1) * VS, p - 1, par[j - 1] - P.aux[p - 1], par[k - 1] - P.aux[p],
+        if (phase == 2) f = P.lotf[(size_t)g * P.lot_max + il];
+        else if (usem) f = f_mvn_rows<2>(m, P.auxT, P.mvn_norm, DLv + (size_t)(i - 1) * VS, p - 1, par[j - 1] - P.aux[p - 1], par[k - 1] - P.aux[p],
                                     DRv + (size_t)(q - 1) * VS);
         else if (FUN == FUN_ISING && P.ising_id != 1 && P.deTL) {
             const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
@@ -978,6 +1079,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         if (a > ba || (a == ba && il < bi)) { ba = a; bv = b; bi = il; }
     }
     STAMP(gs, 0);   // 3: selection + eval + ddot
+    if (phase == 1) { if (tid == 0) gs.S[0] = st; return; }
     if (HOST_PASS1(FUN, P)) return;
     ma = block_max(ma, sha);
     block_argmax(ba, bv, bi, sha, shv, shi);
@@ -1043,13 +1145,13 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     STAMP_DECL;
     if (tid == 0) {
         cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]);
-        if (mode == 3) { cur.kk = (int)blockIdx.z % cur.n2 + 1; cur.qq = (int)blockIdx.z / cur.n2 + 1; }   // :356-369 column (k,q)
+        if (mode == 3 || mode == 4) { cur.kk = (int)blockIdx.z % cur.n2 + 1; cur.qq = (int)blockIdx.z / cur.n2 + 1; }   // :356-369 column (k,q)
     }
     __syncthreads();
-    if (mode == 3) { if (!cur.active || (int)blockIdx.z >= cur.n2 * cur.r2) return; }
+    if (mode == 3 || mode == 4) { if (!cur.active || (int)blockIdx.z >= cur.n2 * cur.r2) return; }
     else if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
     STAMP(gs, 1);   // 0: resolve
-    const bool iscol = (mode == 3) ? true : (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
+    const bool iscol = (mode == 3 || mode == 4) ? true : (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
     const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
     const int nf = iscol ? r0 * n1 : n2 * r2;
     if ((int)(blockIdx.x * TTX_BLK) >= nf) return;
@@ -1142,7 +1244,8 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             else       { sx.pa = fxs; sx.A = p; sx.self = u + 1; sx.pb = vt + (size_t)v * VS; }
             a = eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + t);         // :520-526 / :553-559
         }
-        if (mode != 3) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
+        if (mode == 4) P.sb[(size_t)g * ((size_t)P.RM * P.NM) * ((size_t)P.RM * P.NM) + (size_t)nf * blockIdx.z + t] = a;   // superblock column (k,q)
+        else if (mode != 3) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
     }
     STAMP(gs, 1);   // 2: eval
     if (HOST_PASS1(FUN, P)) return;
@@ -1178,7 +1281,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             } else gs.Pt[h & 1][blockIdx.x] = pr;
         }
     }
-    if (mode == 3) {
+    if (mode == 3 || mode == 4) {
         if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) gs.neval += (long long)r0 * n1 * n2 * r2;   // :372
         return;
     }
@@ -1658,6 +1761,24 @@ __global__ __launch_bounds__(256) void k_exch_max_apply(DevProb P, int from_recv
     if (do_apply) exch_apply_group(P, g);
 }
 
+// one element per wave (ttx_de.h)
+template <bool FAST> __device__ __forceinline__ double de_elem_full(int m, const double *xv, double *T2, int lane);
+__device__ __forceinline__ double de_finish_vals(int id, double a, int m, const double *xv, const double *wv);
+// corner entry of the Ising D / E integrands by the first wave of the block: multi-index = rowA (dims 1..p-1) | self | rowB
+__device__ __forceinline__ double de_corner_wave(const DevProb &P, const double *par, const short *rowA, int p, int self, const short *rowB,
+                                                 double *scratch, int lane)
+{
+    const int m = P.d, VS = ((m + 7) & ~7) + 8, n1m = P.n[1];
+    double *xv = scratch, *wv = xv + VS, *T2 = wv + VS;
+    for (int x = lane; x < m; x += 64) {
+        const int ix = ((x < p - 1) ? (int)rowA[x] : (x == p - 1) ? self : (int)rowB[x - p]) - 1;
+        xv[x] = par[ix]; wv[x] = par[n1m + ix];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double a = P.de_unit ? de_elem_full<true>(m, xv, T2, lane) : de_elem_full<false>(m, xv, T2, lane);
+    return de_finish_vals(P.ising_id, a, m, xv, wv);
+}
+
 // grow the boundary cores with the neighbours' fibers, evaluate the corner entries, LU-apply
 // blocks [0,NM): "share blocks to the LEFT" receive side (:912-952), one mode index k each;
 // blocks [NM,2NM): "share blocks to the RIGHT" receive side (dmrggmp.f90:598-627), one mode index j each
@@ -1677,6 +1798,9 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
     const int VSr = ((m + 7) & ~7) + 8;
     short *rowA = (short *)(((size_t)(dyn + P.npar) + 15) & ~(size_t)15), *rowB = rowA + VSr;
     double *lu = (double *)(rowB + VSr);                  // packed LU of the boundary bond (ranks <= 64)
+    double *wscr = lu + 64 * 64 + 4;                      // scratch of the one-element-per-wave evaluator (Ising D/E, P.bnd_wave)
+    __shared__ double s_corner;
+    const bool dewave = (FUN == FUN_ISING) && P.ising_id != 1 && P.bnd_wave;
     if ((int)blockIdx.x < P.NM) {
         const int k = blockIdx.x, p = last, br = last + 1;
         if (!P.inR[g] || !upd[br] || k >= P.n[br]) return;
@@ -1692,9 +1816,13 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
             auto dimv = [&](int s) -> short { return (s < p) ? Lt[(size_t)(s - 1) * P.RM + (vp[0] - 1)] : (s == p) ? (short)vp[1] : (s == p + 1) ? (short)(k + 1) : Rt[(size_t)(s - p - 2) * P.RM + snew]; };
             for (int x = tid; x < VSr; x += TTX_BLK) { rowA[x] = (x < p - 1) ? dimv(x + 1) : (short)1; rowB[x] = (x < m - p) ? dimv(p + 1 + x) : (short)1; }
             __syncthreads();
+            if (dewave) {
+                if (tid < 64) { const double c_ = de_corner_wave(P, par, rowA, p, (int)vp[1], rowB, wscr, tid); if (tid == 0) s_corner = c_; }
+                __syncthreads();
+            }
             if (tid == rrp) {
                 Src3 sx{rowA, p - 1, (int)vp[1], rowB};
-                a = eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + k);
+                a = dewave ? s_corner : eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + k);
                 if (!HOST_PASS1(FUN, P)) {
                     atomic_max_pos(&gs.amax, fabs(a));
                     if (k == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n2);   // :936
@@ -1740,9 +1868,13 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
             auto dimv = [&](int s) -> short { return (s < p) ? Lt[(size_t)(s - 1) * P.RM + inew] : (s == p) ? (short)(j + 1) : (s == p + 1) ? (short)vp[2] : Rt[(size_t)(s - p - 2) * P.RM + (vp[3] - 1)]; };
             for (int x = tid; x < VSr; x += TTX_BLK) { rowA[x] = (x < p - 1) ? dimv(x + 1) : (short)1; rowB[x] = (x < m - p) ? dimv(p + 1 + x) : (short)1; }
             __syncthreads();
+            if (dewave) {
+                if (tid < 64) { const double c_ = de_corner_wave(P, par, rowA, p, j + 1, rowB, wscr, tid); if (tid == 0) s_corner = c_; }
+                __syncthreads();
+            }
             if (tid == rrp) {
                 Src3 sx{rowA, p - 1, j + 1, rowB};
-                y = eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + P.NM + j);
+                y = dewave ? s_corner : eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + P.NM + j);
                 if (!HOST_PASS1(FUN, P)) {
                     atomic_max_pos(&gs.amax, fabs(y));
                     if (j == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n1);
