@@ -34,6 +34,10 @@ WORKLOADS = {
     # BASELINE config 4 at full size (4 bond groups by default): about 3 s per step
     "mvn128": (("mvn", "mvn", 128, 33, 50, 2), "mvn d=128 n=33 r=50 piv=2 (multivariate-normal density, test_crs_mvn)"),
 }
+# tt_lib utilities on the RESULT train of a sweep: `ort` = dtt_ort (left-to-right Householder QR), `svd` = dtt_svd
+# (ort + truncated SVD right-to-left, tol 1e-10); the sweep that produces the train is not timed
+UTIL_WORKLOADS = {"ort": "c64", "svd": "c64", "ort_d64": "d64", "svd_d64": "d64"}
+WORKLOADS["d64"] = (("ising", "d", 64, 51, 32, 2), "Ising D_64 n=51 r=32 piv=2 (d=63)")
 LONG_WORKLOADS = {"d256", "mvn128"}     # one CPU run takes minutes: cpu_baseline times a bounded prefix of one run
 FP64_VECTOR_PEAK_TFLOPS = 78.0      # MI355X fp64 vector (non-matrix) peak, SURVEY 8(d)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -160,6 +164,49 @@ def cpu_baseline_prefix(argv, limit_s=None):
                       f"OMP_NUM_THREADS={cores}): {last[0]} evaluations up to sweep {last[2]}"}
 
 
+def bench_utility(a, D, E):
+    """`--workload ort|svd[_d64]`: dtt_ort / dtt_svd (lib/tt.f90:130-198, 307-368) on the finalised train of a sweep, one GPU.
+    A step = one call on a fresh copy of that train (the upload of the copy is not timed).  Reported against the HBM
+    roofline with the algorithmic traffic of one pass over the cores per stage (ort: read + write every core once;
+    svd: ort plus a second read + write), and the Householder flop count against the fp64 MATRIX peak for reference."""
+    import numpy as np
+    base = UTIL_WORKLOADS[a.workload]
+    argv, desc = WORKLOADS[base]
+    s = D.ising_setup(argv[1], argv[2], argv[3])
+    src = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=8).run()
+    cores = [src.core(k) for k in range(1, src.d + 1)]
+    r = src.ranks()
+    op = a.workload.split("_")[0]
+    times = []
+    out_ranks = None
+    for it in range(a.warmup + a.steps):
+        t = E.TTCross.from_cores(cores)
+        t0 = time.perf_counter()
+        if op == "ort":
+            t.ort()
+        else:
+            t.svd(1e-10)
+        dt = time.perf_counter() - t0
+        if it >= a.warmup:
+            times.append(dt)
+        out_ranks = t.ranks()
+        nrm = t.norm()
+        t.close()
+    sz = sum(c.size for c in cores)
+    passes = 2 if op == "ort" else 4
+    ms = 1e3 * sum(times) / len(times)
+    flops = sum(2.0 * (r[k] * s["n"][k]) * r[k + 1] ** 2 * 2 for k in range(src.d))      # QR + forming Q, per core
+    line = {"metric": f"tt_lib {('dtt_ort' if op == 'ort' else 'dtt_svd')} on the result train of {desc}", "value": src.d / (ms * 1e-3), "unit": "cores/s",
+            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "the finalised cores of a dtt_dmrgg run (synthetic integrand)",
+            "config": {"workload": a.workload, "cores": src.d, "doubles": int(sz), "ranks_in_max": int(max(r)), "ranks_out_max": int(max(out_ranks)), "norm": nrm},
+            "roofline": {"kernel": "k_qr (+ k_gemm_mfma, k_jacobi_svd)", "bound": "hbm", "achieved": passes * 8.0 * sz / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": passes * 8.0 * sz / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_step": passes * 8.0 * sz, "householder_flops_per_step": flops,
+                         "note": "63 dependent per-core stages of < 0.5 MB each: launch- and latency-bound, see DESIGN.md section 8"}}
+    print(json.dumps(line))
+
+
 def tt_own(nproc, d):
     """share(1, d-1, nproc) of lib/default.f90:78-97: own(0:nproc)."""
     first, last = 1, d - 1
@@ -171,7 +218,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c64", choices=sorted(WORKLOADS) + sorted(UTIL_WORKLOADS))
     ap.add_argument("--no-extras", action="store_true", help="skip the k2_streaming and single_group side measurements (profiler runs: only the workload's own launches)")
     ap.add_argument("--groups", type=int, default=0, help="bond groups = MPI ranks of the reference's domain split; default 8 (config 3 of BASELINE.json) at every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -204,6 +251,8 @@ def main():
     from ttcross_amd import drivers as D
     from ttcross_amd import engine as E
 
+    if a.workload in UTIL_WORKLOADS:
+        return bench_utility(a, D, E)
     argv, desc = WORKLOADS[a.workload]
     s = D.ising_setup(argv[1], argv[2], argv[3]) if argv[0] == "ising" else D.box_setup(argv[0], argv[2], argv[3])
     groups = a.groups or max(4 if a.workload == "mvn128" else 8, world)

@@ -161,6 +161,12 @@ int ttx_from_tt(ttx_engine **out, int32_t d, const int32_t *n, const int32_t *r,
 int ttx_write(const ttx_engine *h, const char *path);
 int ttx_read(ttx_engine **out, const char *path, int32_t device);
 int ttx_get_modes(const ttx_engine *h, int32_t *d, int32_t *n);
+/* save_dtt_to_hdf5 (lib/utils.f90:8-57): group "TT", datasets "modes", "ranks" (native int) and "core_k", k = 0..m-1, with
+ * the Fortran shape (r(k-1), n(k), r(k)); ttx_read_hdf5 loads such a file into a new engine (the reference has no
+ * reader; this one exists for round trips and checkpoints).  libhdf5.so is resolved at run time (dlopen): without it both
+ * return TTX_EINVAL with a message. */
+int ttx_write_hdf5(const ttx_engine *h, const char *path);
+int ttx_read_hdf5(ttx_engine **out, const char *path, int32_t device);
 
 /* profiling: with on != 0 the next ttx_run brackets every kernel launch with HIP events on the engine's
  * stream; ttx_kernel_stats then reports, per kernel kind, launches and total milliseconds. */

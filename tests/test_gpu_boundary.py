@@ -99,9 +99,63 @@ def test_fortran_driver_with_user_callback(userfun, mode, monkeypatch):
     assert abs(val - oo["value"]) <= 1e-15 * abs(val)
 
 
-def test_fortran_tt_generics():
+def _h5(tool, *args):
+    exe = os.path.join("/opt/conda/bin", tool)
+    if not os.path.exists(exe):
+        pytest.skip(f"{tool} not on this box")
+    return subprocess.run([exe] + list(args), capture_output=True, text=True, check=True).stdout
+
+
+def test_hdf5_layout_of_the_reference(tmp_path):
+    """N3: save_dtt_to_hdf5 (lib/utils.f90:8-57) -- group TT, datasets modes / ranks (native int) and core_k with the Fortran
+    shape (r(k-1), n(k), r(k)), i.e. the C dataspace reversed.  Checked with the HDF5 command-line tools and by reading
+    the file back into an engine."""
+    s = D.ising_setup("c", 6, 17)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], 7, pivoting=2, accuracy=s["acc"], quad=s["quad"]).run()
+    f = str(tmp_path / "tt.h5")
+    try:
+        tt.write_hdf5(f)
+    except E.TTXError as e:
+        if "libhdf5" in str(e):
+            pytest.skip("no libhdf5 on this box")
+        raise
+    r, n = tt.ranks(), s["n"]
+    ls = _h5("h5ls", "-r", f)
+    assert "/TT" in ls and "/TT/modes" in ls and "/TT/ranks" in ls
+    for k in range(tt.d):
+        line = [ln for ln in ls.splitlines() if ln.split()[0] == f"/TT/core_{k}"][0]
+        assert "{%d, %d, %d}" % (r[k + 1], n[k], r[k]) in line, line
+    dump = _h5("h5dump", "-d", "/TT/ranks", f)
+    assert "H5T_STD_I32LE" in dump
+    vals = [int(v) for v in dump.split("DATA {")[1].split("}")[0].replace("(0):", "").replace(",", " ").split()]
+    assert vals == list(r)
+    core2 = _h5("h5dump", "-d", "/TT/core_2", "-y", "-w", "1", f).split("DATA {")[1].split("}")[0]
+    got = np.array([float(v.strip(", ")) for v in core2.split() if v.strip(", ")])
+    assert np.array_equal(got, tt.core(3).ravel(order="F"))              # file bytes = Fortran column-major core
+    t2 = E.TTCross.read_hdf5(f)
+    assert np.array_equal(t2.ranks(), r)
+    assert all(np.array_equal(t2.core(k), tt.core(k)) for k in range(1, tt.d + 1))
+    assert t2.quad(s["quad"]) == tt.quad(s["quad"])
+
+
+def test_cos_approx_pdf_from_the_characteristic_function():
+    """N2 tail: the COS-method density (lib/cos_approx.f90) from the 32 complex quadratures of the chf pipeline
+    (test_crs_pdf.f90:153-190).  The density of the basket average must be non-negative up to the truncation ripple,
+    integrate to ~1 over [0, 300] and agree with the direct cosine sum."""
+    tt, xs, pdf = D.run_pdf(["4", "17", "8", "2"], verbose=False)
+    vals = tt.zquad(D.chf_weights(D.box_setup("mvn", 4, 17)["par"], 17, 4))
+    k = np.arange(32)
+    w = k * np.pi / 300.0
+    c = 2.0 / 300.0 * vals.real
+    c[0] /= 2
+    assert np.allclose(pdf, np.cos(np.outer(xs, w)) @ c, rtol=0, atol=1e-15)
+    assert abs(np.trapz(pdf, xs) - vals[0].real) < 5e-3 * abs(vals[0].real)
+
+
+def test_fortran_tt_generics(tmp_path):
     """Host-side generics of the drop-in tt_lib and mat_lib; `b = a` deep copy with disjoint ownership."""
-    p = subprocess.run([fortran_exe("test_tt_generics")], capture_output=True, text=True, timeout=300)
+    h5 = str(tmp_path / "gen.h5")
+    p = subprocess.run([fortran_exe("test_tt_generics"), h5], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     out = {ln.split()[0]: ln.split()[1:] for ln in p.stdout.splitlines() if ln.strip()}
     n = [2, 3, 4, 5]
@@ -120,6 +174,13 @@ def test_fortran_tt_generics():
     assert [int(v) for v in out["svd_ranks"]] == [1, 1, 1, 1, 1] and abs(float(out["svd_norm"][0]) - 2 * nrm) < 1e-5
     assert float(out["zeros_sumall"][0]) == 0.0 and abs(float(out["copy_sumall"][0]) - tot) < 1e-9
     assert float(out["matinv_err"][0]) < 1e-14 and float(out["svd_err"][0]) < 1e-13 and int(out["chop"][0]) == 2
+    phis = np.array([1.0, 0.5 - 0.25j, -0.125 + 0.0625j, 0.03 + 0.01j])
+    want = D.cos_approximate([0.5, 1.25, 2.75], phis, 0.25, 3.0, 4)
+    assert np.allclose([float(v) for v in out["cos_array"]], want, rtol=1e-14, atol=1e-16)
+    assert abs(float(out["cos_point"][0]) - want[1]) <= 1e-14 * abs(want[1])
+    if "hdf5_written" in out and os.path.exists("/opt/conda/bin/h5ls"):
+        ls = _h5("h5ls", "-r", h5)
+        assert "/TT/core_3" in ls and "{1, 5, 1}" in [ln for ln in ls.splitlines() if ln.startswith("/TT/core_3")][0]
     assert "dealloc_ok" in out
 
 

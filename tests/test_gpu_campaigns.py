@@ -1,0 +1,114 @@
+"""Randomised and repeated-run campaigns on the GPU (the scripts behind the figures DESIGN.md section 2 quotes).
+
+Inside `pytest -m gpu` they run a SMALL sample (seconds); a campaign is the same code with more cases:
+
+    TTX_FUZZ_CASES=2000 TTX_FUZZ_SEED=7 python -m pytest tests/test_gpu_campaigns.py -m gpu -q -k fuzz
+    TTX_SOAK_RUNS=500 python -m pytest tests/test_gpu_campaigns.py -m gpu -q -k soak
+    TTX_MPFUZZ_CASES=40 python -m pytest tests/test_gpu_campaigns.py -m gpu -q -k multi_process
+
+Every case is compared with the CPU oracle bit for bit (tapes, per-sweep records, integral); a failing case prints the
+arguments that reproduce it."""
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ttcross_amd import drivers as D
+from ttcross_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _random_case(rng):
+    kind = rng.choice(["c", "c", "c", "d", "e", "stdnorm", "mvn"])
+    if kind in ("c", "d", "e"):
+        m = int(rng.integers(3, 40 if kind == "c" else 14))
+        d = m - 1
+    else:
+        m = d = int(rng.integers(2, 14))
+    n = int(rng.choice([2, 3, 5, 9, 17, 25, 33, 41]))
+    r = int(rng.integers(2, 40 if kind == "c" else 14))
+    piv = int(rng.choice([-1, 0, 1, 2, 3, 4])) if r * n <= 160 else int(rng.choice([0, 1, 2, 3]))
+    ng = int(rng.integers(1, min(5, d - 1) + 1)) if d > 2 else 1
+    return kind, m, n, r, piv, ng
+
+
+def _setup(kind, m, n):
+    if kind in ("c", "d", "e"):
+        return D.ising_setup(kind, m, n)
+    s = D.box_setup(kind, m, n)
+    if kind == "mvn":
+        s["aux"] = O.mvn_init(m)
+    return s
+
+
+def _compare(kind, m, n, r, piv, ng):
+    s = _setup(kind, m, n)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=ng).run()
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=ng)
+    ok = (np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d]) and
+          [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]] and
+          [a["neval"] for a in tt.sweeps()] == [b["neval"] for b in oo["sweeps"]] and
+          [a["amax"] for a in tt.sweeps()] == [b["amax"] for b in oo["sweeps"]] and
+          tt.quad(s["quad"]) == oo["value"])
+    val = tt.quad(s["quad"])
+    tt.close()
+    return ok, val
+
+
+def test_fuzz_random_shapes_vs_oracle():
+    """Random integrand, dimension, mode size, rank, pivoting mode and number of bond groups."""
+    ncases = int(os.environ.get("TTX_FUZZ_CASES", "12"))
+    rng = np.random.default_rng(int(os.environ.get("TTX_FUZZ_SEED", "20261004")))
+    bad = []
+    for _ in range(ncases):
+        case = _random_case(rng)
+        ok, _ = _compare(*case)
+        if not ok:
+            bad.append(case)
+    assert not bad, f"cases that differ from the oracle (kind, m, n, r, piv, groups): {bad}"
+
+
+def test_soak_repeated_runs_are_identical():
+    """The same engine run again and again (cluster kernel: its record tags and barrier counters carry over between
+    launches) must return the identical integral and evaluation count every time."""
+    runs = int(os.environ.get("TTX_SOAK_RUNS", "25"))
+    for kind, m, n, r, piv, ng in [("c", 64, 51, 32, 2, 8), ("c", 20, 17, 24, 3, 3), ("d", 8, 17, 8, 2, 2)]:
+        s = _setup(kind, m, n)
+        tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng)
+        ref = None
+        for _ in range(runs):
+            tt.run()
+            cur = (tt.quad(s["quad"]), tt.neval, len(tt.sweeps()))
+            ref = ref or cur
+            assert cur == ref, (kind, m, n, r, piv, ng, cur, ref)
+        assert tt.cluster_fallbacks == 0
+        tt.close()
+
+
+def test_fuzz_multi_process_jobs():
+    """Random jobs as 2-4 engine processes over the shared-memory transport (tests/mp_worker.py checks each against the oracle)."""
+    ncases = int(os.environ.get("TTX_MPFUZZ_CASES", "3"))
+    rng = np.random.default_rng(int(os.environ.get("TTX_FUZZ_SEED", "20261004")) + 1)
+    for _ in range(ncases):
+        world = int(rng.integers(2, 5))
+        kind = str(rng.choice(["c", "c", "d", "e"]))
+        m = int(rng.integers(world + 3, 24 if kind == "c" else 11))
+        n = int(rng.choice([5, 9, 17, 33]))
+        r = int(rng.integers(3, 20 if kind == "c" else 9))
+        piv = int(rng.choice([0, 1, 2, 3]))
+        ng = int(rng.integers(world, min(2 * world, m - 2) + 1))
+        name = "ttx_" + uuid.uuid4().hex[:12]
+        procs = []
+        for rk in range(world):
+            env = dict(os.environ, RANK=str(rk), WORLD_SIZE=str(world), TTX_SHM_NAME=name)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), kind, str(m), str(n), str(r), str(piv), str(ng), "shm"],
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+        for p in procs:
+            o, e = p.communicate(timeout=600)
+            assert p.returncode == 0 and " OK" in o, f"world={world} {kind} {m} {n} {r} {piv} groups={ng}\n" + o[-1500:] + e[-1500:]

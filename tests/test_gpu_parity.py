@@ -281,6 +281,25 @@ def test_multi_process_bond_split(world, args):
     assert out.stdout.count(" OK") == world
 
 
+def test_rccl_transport_on_real_gpus():
+    """The in-library RCCL transport (ncclSend/ncclRecv + ncclAllReduce on the engine's stream) needs one GPU per rank:
+    skipped on a one-GPU box.  Until this has passed somewhere the RCCL path is EXPERIMENTAL."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    world = 2
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs (have {torch.cuda.device_count()}): the RCCL transport has never moved data yet")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "tests", "mp_worker.py")] + "c 64 51 32 2 8".split() + ["rccl"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count(" OK") == world
+
+
 def _spawn_ranks(world, argv, extra_env=None, timeout=600):
     """`world` processes with RANK / WORLD_SIZE (and the TTX_WORLD_* twins the Fortran layer reads), a fresh shm name each."""
     import os

@@ -1457,6 +1457,128 @@ extern "C" int ttx_write(const ttx_engine *h, const char *path)
     return TTX_OK;
 }
 
+// ---- HDF5 layout of lib/utils.f90:8-57 (save_dtt_to_hdf5): group "TT", datasets "modes" (m ints), "ranks" (m+1 ints),
+//      "core_k" (k = 0..m-1) with the Fortran shape (r(k-1), n(k), r(k)) -- i.e. the C dataspace (r(k), n(k), r(k-1)) over the
+//      column-major bytes.  libhdf5 is an optional run-time dependency, resolved with dlopen like librccl.
+namespace {
+typedef int64_t hid_t_; typedef int herr_t_; typedef unsigned long long hsize_t_;
+struct Hdf5Api {
+    void *lib = nullptr;
+    herr_t_ (*open)() = nullptr;
+    hid_t_ (*Fcreate)(const char *, unsigned, hid_t_, hid_t_) = nullptr;
+    hid_t_ (*Fopen)(const char *, unsigned, hid_t_) = nullptr;
+    herr_t_ (*Fclose)(hid_t_) = nullptr;
+    hid_t_ (*Gcreate2)(hid_t_, const char *, hid_t_, hid_t_, hid_t_) = nullptr;
+    herr_t_ (*Gclose)(hid_t_) = nullptr;
+    hid_t_ (*Screate_simple)(int, const hsize_t_ *, const hsize_t_ *) = nullptr;
+    herr_t_ (*Sclose)(hid_t_) = nullptr;
+    hid_t_ (*Dcreate2)(hid_t_, const char *, hid_t_, hid_t_, hid_t_, hid_t_, hid_t_) = nullptr;
+    hid_t_ (*Dopen2)(hid_t_, const char *, hid_t_) = nullptr;
+    hid_t_ (*Dget_space)(hid_t_) = nullptr;
+    int (*Sget_simple_extent_dims)(hid_t_, hsize_t_ *, hsize_t_ *) = nullptr;
+    herr_t_ (*Dwrite)(hid_t_, hid_t_, hid_t_, hid_t_, hid_t_, const void *) = nullptr;
+    herr_t_ (*Dread)(hid_t_, hid_t_, hid_t_, hid_t_, hid_t_, void *) = nullptr;
+    herr_t_ (*Dclose)(hid_t_) = nullptr;
+    herr_t_ (*Eset_auto2)(hid_t_, void *, void *) = nullptr;
+    hid_t_ t_int = -1, t_double = -1;
+};
+Hdf5Api g_h5;
+int hdf5_load()
+{
+    if (g_h5.lib) return TTX_OK;
+    void *L = nullptr;
+    for (const char *nm : {"libhdf5.so", "libhdf5.so.103", "/opt/conda/lib/libhdf5.so", "libhdf5_serial.so"}) if ((L = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!L) return fail(TTX_EINVAL, "save_dtt_to_hdf5: libhdf5.so not found (%s)", dlerror());
+#define H5_(f, name) *(void **)(&g_h5.f) = dlsym(L, name); if (!g_h5.f) return fail(TTX_EINVAL, "libhdf5.so lacks %s", name);
+    H5_(open, "H5open") H5_(Fcreate, "H5Fcreate") H5_(Fopen, "H5Fopen") H5_(Fclose, "H5Fclose") H5_(Gcreate2, "H5Gcreate2") H5_(Gclose, "H5Gclose")
+    H5_(Screate_simple, "H5Screate_simple") H5_(Sclose, "H5Sclose") H5_(Dcreate2, "H5Dcreate2") H5_(Dopen2, "H5Dopen2") H5_(Dget_space, "H5Dget_space")
+    H5_(Sget_simple_extent_dims, "H5Sget_simple_extent_dims") H5_(Dwrite, "H5Dwrite") H5_(Dread, "H5Dread") H5_(Dclose, "H5Dclose") H5_(Eset_auto2, "H5Eset_auto2")
+#undef H5_
+    if (g_h5.open() < 0) return fail(TTX_EINVAL, "H5open failed");
+    hid_t_ *ti = (hid_t_ *)dlsym(L, "H5T_NATIVE_INT_g"), *td = (hid_t_ *)dlsym(L, "H5T_NATIVE_DOUBLE_g");
+    if (!ti || !td) return fail(TTX_EINVAL, "libhdf5.so lacks the native type ids");
+    g_h5.t_int = *ti; g_h5.t_double = *td;
+    g_h5.Eset_auto2(0, nullptr, nullptr);                      // errors are reported through return codes here
+    g_h5.lib = L;
+    return TTX_OK;
+}
+}
+extern "C" int ttx_write_hdf5(const ttx_engine *h, const char *path)
+{
+    if (!h || !path || !h->ran) return fail(TTX_ESTATE, "save_dtt_to_hdf5: no tensor train to write");
+    if (h->W > 1) return fail(TTX_EINVAL, "save_dtt_to_hdf5: single-process engines only");
+    int rc = hdf5_load();
+    if (rc) return rc;
+    const int d = h->d;
+    const hid_t_ f = g_h5.Fcreate(path, 2u /* H5F_ACC_TRUNC */, 0, 0);
+    if (f < 0) return fail(TTX_EINVAL, "save_dtt_to_hdf5: cannot create %s", path);
+    const hid_t_ grp = g_h5.Gcreate2(f, "TT", 0, 0, 0);
+    bool ok = grp >= 0;
+    auto put = [&](const char *name, int rank, const hsize_t_ *dims, hid_t_ type, const void *buf) {
+        const hid_t_ sp = g_h5.Screate_simple(rank, dims, nullptr);
+        const hid_t_ ds = (sp >= 0) ? g_h5.Dcreate2(grp, name, type, sp, 0, 0, 0) : -1;
+        if (ds < 0 || g_h5.Dwrite(ds, type, 0, 0, 0, buf) < 0) ok = false;
+        if (ds >= 0) g_h5.Dclose(ds);
+        if (sp >= 0) g_h5.Sclose(sp);
+    };
+    if (ok) {
+        hsize_t_ d1 = (hsize_t_)d;
+        put("modes", 1, &d1, g_h5.t_int, &h->n1[1]);                                 // utils.f90:25-30
+        d1 = (hsize_t_)d + 1;
+        put("ranks", 1, &d1, g_h5.t_int, h->rfinal.data());                          // :32-37
+        std::vector<double> x;
+        for (int k = 1; k <= d && ok; k++) {                                         // :40-51
+            x.resize((size_t)ttx_core_size(h, k));
+            if ((rc = ttx_get_core(h, k, x.data()))) { ok = false; break; }
+            const hsize_t_ d3[3] = {(hsize_t_)h->rfinal[k], (hsize_t_)h->n1[k], (hsize_t_)h->rfinal[k - 1]};   // Fortran (r0, n, r1) reversed
+            char nm[32]; snprintf(nm, sizeof nm, "core_%d", k - 1);
+            put(nm, 3, d3, g_h5.t_double, x.data());
+        }
+    }
+    if (grp >= 0) g_h5.Gclose(grp);
+    g_h5.Fclose(f);
+    if (!ok) return rc ? rc : fail(TTX_EINVAL, "save_dtt_to_hdf5: error writing %s", path);
+    return TTX_OK;
+}
+extern "C" int ttx_read_hdf5(ttx_engine **out, const char *path, int32_t device)
+{
+    if (!out || !path) return fail(TTX_EINVAL, "ttx_read_hdf5: null argument");
+    *out = nullptr;
+    int rc = hdf5_load();
+    if (rc) return rc;
+    const hid_t_ f = g_h5.Fopen(path, 0u /* H5F_ACC_RDONLY */, 0);
+    if (f < 0) return fail(TTX_EINVAL, "ttx_read_hdf5: cannot open %s", path);
+    auto dims_of = [&](const char *name, int want, hsize_t_ *dims) -> hid_t_ {
+        const hid_t_ ds = g_h5.Dopen2(f, name, 0);
+        if (ds < 0) return -1;
+        const hid_t_ sp = g_h5.Dget_space(ds);
+        const int nd = (sp >= 0) ? g_h5.Sget_simple_extent_dims(sp, dims, nullptr) : -1;
+        if (sp >= 0) g_h5.Sclose(sp);
+        if (nd != want) { g_h5.Dclose(ds); return -1; }
+        return ds;
+    };
+    hsize_t_ dm[3];
+    std::vector<int32_t> n, r;
+    std::vector<double> cores;
+    bool ok = true;
+    hid_t_ ds = dims_of("/TT/modes", 1, dm);
+    if (ds < 0) ok = false;
+    else { n.resize(dm[0]); ok = g_h5.Dread(ds, g_h5.t_int, 0, 0, 0, n.data()) >= 0; g_h5.Dclose(ds); }
+    if (ok) { ds = dims_of("/TT/ranks", 1, dm); if (ds < 0 || dm[0] != n.size() + 1) ok = false; if (ds >= 0) { r.resize(dm[0]); ok = ok && g_h5.Dread(ds, g_h5.t_int, 0, 0, 0, r.data()) >= 0; g_h5.Dclose(ds); } }
+    for (size_t k = 0; ok && k < n.size(); k++) {
+        char nm[40]; snprintf(nm, sizeof nm, "/TT/core_%zu", k);
+        ds = dims_of(nm, 3, dm);
+        if (ds < 0 || (int)dm[0] != r[k + 1] || (int)dm[1] != n[k] || (int)dm[2] != r[k]) { ok = false; if (ds >= 0) g_h5.Dclose(ds); break; }
+        const size_t off = cores.size(), sz = (size_t)r[k] * n[k] * r[k + 1];
+        cores.resize(off + sz);
+        ok = g_h5.Dread(ds, g_h5.t_double, 0, 0, 0, cores.data() + off) >= 0;
+        g_h5.Dclose(ds);
+    }
+    g_h5.Fclose(f);
+    if (!ok) return fail(TTX_EINVAL, "ttx_read_hdf5: %s does not hold a tensor train in the layout of lib/utils.f90", path);
+    return ttx_from_tt(out, (int32_t)n.size(), n.data(), r.data(), cores.data(), device);
+}
+
 extern "C" int ttx_read(ttx_engine **out, const char *path, int32_t device)
 {
     if (!out || !path) return fail(TTX_EINVAL, "dtt_read: null argument");

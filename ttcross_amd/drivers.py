@@ -125,6 +125,30 @@ def chf_weights(par, n, d, nfreq=32, upper=300.0):
     return np.array([np.tile(w * np.exp(1j * (k * math.pi / upper) * np.exp(x) / d), d) for k in range(nfreq)])
 
 
+def cos_approximate(xs, phis, lower_bound, upper_bound, n_terms=None):
+    """lib/cos_approx.f90: COS-method density at the points xs from characteristic-function values phis[k] = phi(k pi/(b-a)):
+    f(x) ~ sum' 2/(b-a) Re(phi_k exp(-i w_k a)) cos(w_k (x - a)), first term halved (test_crs_pdf.f90:190)."""
+    phis = np.asarray(phis, dtype=np.complex128)
+    n = len(phis) if n_terms is None else n_terms
+    if n > len(phis):
+        raise ValueError("n_terms exceeds the size of phis")
+    w = np.arange(n) * (math.pi / (upper_bound - lower_bound))
+    c = 2.0 / (upper_bound - lower_bound) * np.real(phis[:n] * np.exp(-1j * w * lower_bound))
+    c[0] /= 2.0
+    return np.cos(np.outer(np.asarray(xs, dtype=np.float64) - lower_bound, w)) @ c
+
+
+def run_pdf(argv, device=0, verbose=True, n_pts=200, upper=300.0):
+    """test_crs_pdf.f90: the chf pipeline followed by the COS-method density of the basket average on linspace(0, upper)."""
+    tt, vals, s = run_chf(argv, device=device, verbose=False)
+    xs = np.linspace(0.0, upper, n_pts)
+    pdf = cos_approximate(xs, vals, 0.0, upper, 32)
+    if verbose:
+        for x, f in zip(xs, pdf):
+            print("%.16e %.16e" % (x, f))
+    return tt, xs, pdf
+
+
 def run_chf(argv, device=0, verbose=True):
     """test_crs_chf.f90:104-168: TT-cross of the multivariate-normal density WITHOUT a quadrature argument, then the
     characteristic function of the basket average at 32 frequencies as complex rank-1 quadratures of the resident
@@ -146,5 +170,7 @@ def run_chf(argv, device=0, verbose=True):
 if __name__ == "__main__":
     if sys.argv[1] == "chf":
         run_chf(sys.argv[2:])
+    elif sys.argv[1] == "pdf":
+        run_pdf(sys.argv[2:])
     else:
         run_driver(sys.argv[1:])

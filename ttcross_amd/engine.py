@@ -238,6 +238,20 @@ class TTCross:
         _check(load_library().ttx_read(ctypes.byref(h), os.fsencode(path), int(device)))
         return cls._adopt(h)
 
+    def write_hdf5(self, path):
+        """save_dtt_to_hdf5 (lib/utils.f90:8-57): group TT with modes, ranks and core_k."""
+        L = load_library()
+        L.ttx_write_hdf5.argtypes = [c_void_p, ctypes.c_char_p]
+        _check(L.ttx_write_hdf5(self._h, os.fsencode(path)))
+
+    @classmethod
+    def read_hdf5(cls, path, device=0):
+        L = load_library()
+        L.ttx_read_hdf5.argtypes = [POINTER(c_void_p), ctypes.c_char_p, c_int32]
+        h = c_void_p()
+        _check(L.ttx_read_hdf5(ctypes.byref(h), os.fsencode(path), int(device)))
+        return cls._adopt(h)
+
     def write(self, path):
         """dtt_write (lib/ttio.f90:29-108): the resident train in the reference's stream format."""
         _check(load_library().ttx_write(self._h, os.fsencode(path)))

@@ -4,7 +4,12 @@
 program main
  use tt_lib
  use mat_lib
+ use cos_approx_mod
+ use utils
  implicit none
+ double complex :: phis(4)
+ double precision :: pdf(3)
+ character(len=256) :: h5name
  type(dtt) :: a,b,c
  double precision :: s,nrm,nb,e(1)
  double precision,pointer :: u(:,:),sv(:),v(:,:)
@@ -48,6 +53,17 @@ program main
  call svd(mat,u,sv,v)
  write(*,'(a,e12.4)') 'svd_err ',maxval(abs(matmul(u,matmul(reshape([sv(1),0.d0,0.d0,0.d0,sv(2),0.d0,0.d0,0.d0,sv(3)],[3,3]),v))-mat))
  write(*,'(a,i3)') 'chop ',chop([1.d0,1.d-3,1.d-9],tol=1.d-6)
+ ! cos_approx_mod (lib/cos_approx.f90)
+ phis=[(1.d0,0.d0),(0.5d0,-0.25d0),(-0.125d0,0.0625d0),(0.03d0,0.01d0)]
+ call cos_approximate_array([0.5d0,1.25d0,2.75d0],phis,lower_bound=0.25d0,upper_bound=3.d0,n_terms=4,pdf_vals=pdf)
+ write(*,'(a,3e24.16)') 'cos_array ',pdf
+ write(*,'(a,e24.16)') 'cos_point ',cos_approximate(1.25d0,phis,0.25d0,3.d0,4)
+ ! utils: save_dtt_to_hdf5 (lib/utils.f90) of a host train
+ call get_command_argument(1,h5name)
+ if(len_trim(h5name).gt.0)then
+  call save_dtt_to_hdf5(a,trim(h5name))
+  write(*,'(a)') 'hdf5_written'
+ end if
  call dealloc(a); call dealloc(b); call dealloc(c)      ! each releases only its own storage
  write(*,'(a)') 'dealloc_ok'
 end program
