@@ -31,6 +31,7 @@
 #include "../../include/ttx.h"
 #include "ttx_kernels.h"
 #include "ttx_de.h"
+#include "ttx_mvn.h"
 #include "ttx_ttops.h"
 #include "ttx_fused.h"
 #include "ttx_cluster.h"
@@ -136,6 +137,7 @@ struct ttx_engine {
     int de_v2 = 0;                      // Ising D/E: wave-per-pivot half-step kernel k_halfstep_de (ttx_de.h)
     int de_slots = 0; size_t lds_de = 0;
     int lot_wave = 0; size_t lds_dew = 0;   // Ising D/E: lottery candidates and boundary corners one element per wave (ttx_de.h)
+    int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
     hipStream_t qstream = nullptr;      // forked per-sweep quadrature (single-process runs)
@@ -560,6 +562,15 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         rc = dev_alloc(h, &lc, (size_t)h->G); if (rc) { ttx_destroy(h); return rc; }
         P.lotp = lp; P.lot_ctr = lc;
         P.lot_max = nlotmax;
+        if (cfg->fun_id == TTX_FUN_MVN && d <= 64 * MVN_MAXQ && cfg->pivoting >= 0 && (int)RM * ((NM + 63) / 64) <= TTX_MAXPART &&
+            !(getenv("TTX_MVN_V2") && atoi(getenv("TTX_MVN_V2")) == 0)) {
+            int *lcd; double *lf;
+            rc = dev_alloc(h, &lcd, (size_t)h->G * nlotmax * 4); if (rc) { ttx_destroy(h); return rc; }
+            rc = dev_alloc(h, &lf, (size_t)h->G * nlotmax); if (rc) { ttx_destroy(h); return rc; }
+            P.lotc = lcd; P.lotf = lf;
+            h->mvn_v2 = 1; h->de_slots = (int)RM * ((NM + 63) / 64);
+            h->lds_mvn = sizeof(double) * (3 * (size_t)d + 8);
+        }
         if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && P.deTL) {
             int *lcd; double *lf;
             rc = dev_alloc(h, &lcd, (size_t)h->G * nlotmax * 4); if (rc) { ttx_destroy(h); return rc; }
@@ -1107,7 +1118,12 @@ static int run_impl(ttx_engine *h)
                 hipLaunchKernelGGL(k_de_tables, dim3((2 * (d + 1) * h->RM + 255) / 256, G), dim3(256), 0, st, P, dir, pp);
             }
             if (h->cfg.pivoting >= 0) {
-                if (FUN == FUN_ISING && h->lot_wave) {
+                if (FUN == FUN_MVN && h->mvn_v2) {
+                    KScope ks(h, TTX_K_LOTTERY, 3);
+                    hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 1);
+                    hipLaunchKernelGGL(k_lottery_eval_mvn, dim3(P.lot_max, G), dim3(64), h->lds_mvn, st, P);
+                    hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 2);
+                } else if (FUN == FUN_ISING && h->lot_wave) {
                     KScope ks(h, TTX_K_LOTTERY, 3);
                     hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 1);
                     if (P.de_unit) hipLaunchKernelGGL(k_lottery_eval_de<true>, dim3(P.lot_max, G), dim3(64), h->lds_dew, st, P);
@@ -1116,7 +1132,9 @@ static int run_impl(ttx_engine *h)
                 } else
                 { KScope ks(h, TTX_K_LOTTERY); if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_lottery<FUN>, dim3(P.lot_nb, G), dim3(P.lot_nb == 1 ? 512 : 256), h->lds_lot, st, Q, dir, pp, h->lot_vals, 0); })) return rc_; }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
-                if (FUN == FUN_ISING && h->de_v2) {
+                if (FUN == FUN_MVN && h->mvn_v2) {
+                    for (int hh = 0; hh < h->H; hh++) hipLaunchKernelGGL(k_halfstep_mvn, dim3(h->de_slots, G), dim3(64), h->lds_mvn, st, P, hh, dir, h->mode);
+                } else if (FUN == FUN_ISING && h->de_v2) {
                     for (int hh = 0; hh < h->H; hh++) {
                         if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de<true>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
                         else hipLaunchKernelGGL(k_halfstep_de<false>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
