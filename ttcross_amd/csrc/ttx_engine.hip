@@ -135,6 +135,7 @@ struct ttx_engine {
     size_t lds_half = 0, lds_lot = 0, lds_par = 0;
     int half_vals = 0, lot_vals = 0;
     int de_v2 = 0;                      // Ising D/E: wave-per-pivot half-step kernel k_halfstep_de (ttx_de.h)
+    int de_v4 = 0; size_t lds_de4 = 0;  // ... with three divider waves beside the folder wave (k_halfstep_de4)
     int de_slots = 0; size_t lds_de = 0;
     int lot_wave = 0; size_t lds_dew = 0;   // Ising D/E: lottery candidates and boundary corners one element per wave (ttx_de.h)
     int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
@@ -379,6 +380,8 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         h->lds_de = sizeof(double) * (5 * (size_t)(((d + 7) & ~7) + 8) + 128);
         h->de_v2 = cfg->pivoting >= 0 && h->de_slots <= TTX_MAXPART && h->lds_de <= 150 * 1024 &&
                    !(getenv("TTX_DE_V2") && atoi(getenv("TTX_DE_V2")) == 0);
+        h->lds_de4 = sizeof(double) * de4_lds_doubles(d);
+        h->de_v4 = h->de_v2 && h->lds_de4 <= 150 * 1024 && !(getenv("TTX_DE_V4") && atoi(getenv("TTX_DE_V4")) == 0);
     }
     if (cfg->fun_id == TTX_FUN_MVN) {
         std::vector<double> t((size_t)d * d);
@@ -569,6 +572,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
             rc = dev_alloc(h, &lf, (size_t)h->G * nlotmax); if (rc) { ttx_destroy(h); return rc; }
             P.lotc = lcd; P.lotf = lf;
             h->mvn_v2 = 1; h->de_slots = (int)RM * ((NM + 63) / 64);
+            P.bnd_wave = 1;
             h->lds_mvn = sizeof(double) * (3 * (size_t)d + 8);
         }
         if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && P.deTL) {
@@ -1023,6 +1027,9 @@ static int run_impl(ttx_engine *h)
         static size_t a_de0 = 0, a_de1 = 0;
         if (h->de_v2 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<true>), h->lds_de, a_de0)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<false>), h->lds_de, a_de1)))) return rc;
+        static size_t a_d40 = 0, a_d41 = 0;
+        if (h->de_v4 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de4<true>), h->lds_de4, a_d40)) ||
+                         (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de4<false>), h->lds_de4, a_d41)))) return rc;
         static size_t a_lw0 = 0, a_lw1 = 0;
         if (h->lot_wave && ((rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de<true>), h->lds_dew, a_lw0)) ||
                             (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de<false>), h->lds_dew, a_lw1)))) return rc;
@@ -1136,7 +1143,10 @@ static int run_impl(ttx_engine *h)
                     for (int hh = 0; hh < h->H; hh++) hipLaunchKernelGGL(k_halfstep_mvn, dim3(h->de_slots, G), dim3(64), h->lds_mvn, st, P, hh, dir, h->mode);
                 } else if (FUN == FUN_ISING && h->de_v2) {
                     for (int hh = 0; hh < h->H; hh++) {
-                        if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de<true>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
+                        if (h->de_v4) {
+                            if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de4<true>, dim3(h->de_slots, G), dim3(256), h->lds_de4, st, P, hh, dir, h->mode);
+                            else hipLaunchKernelGGL(k_halfstep_de4<false>, dim3(h->de_slots, G), dim3(256), h->lds_de4, st, P, hh, dir, h->mode);
+                        } else if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de<true>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
                         else hipLaunchKernelGGL(k_halfstep_de<false>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
                     }
                 } else
@@ -1177,7 +1187,7 @@ static int run_impl(ttx_engine *h)
             if (nproc > 1) {
                 const size_t VSb = ((d + 7) & ~7) + 8;
                 const size_t lds_b = h->lds_par + 16 + sizeof(short) * 2 * VSb + sizeof(double) * (64 * 64 + 4) +
-                                     (P.bnd_wave ? sizeof(double) * (2 * VSb + (size_t)DE_RT * (VSb + 1) + 8) : 0);
+                                     (P.bnd_wave ? sizeof(double) * (2 * VSb + (size_t)DE_RT * (VSb + 1) + 8) : 0);    // >= the 3 d doubles of the mvn corner
                 static size_t a_bnd = 0;
                 if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_exch_boundary<FUN>), lds_b, a_bnd)) return rc_;
                 if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), lds_b, st, Q); })) return rc_;
@@ -2101,6 +2111,74 @@ __global__ __launch_bounds__(64) void k_latency_probe(const unsigned *ring, doub
         out[5] = x + s + (double)p + (double)q + z;      // keep the chains alive
     }
 }
+// development probe: ns per element of the LDS-broadcast folds (one wave per block, `nblk` blocks), rows of `len` doubles
+__global__ __launch_bounds__(64) void k_fold_probe(int len, int reps, double *out)
+{
+    __shared__ double row[1024];
+    const int lane = threadIdx.x;
+    for (int x = lane; x < 1024; x += 64) row[x] = 1.0 + 1e-9 * x;
+    __syncthreads();
+    double a = 1.0, s = 0.0;
+    long long t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) a = lds_chain(a, row + (r & 7), len);
+    long long t1 = wall_clock64();
+    for (int r = 0; r < reps; r++) s = lds_sum_chain(s, row + (r & 7), len);
+    long long t2 = wall_clock64();
+    double u = 0.7 + 1e-9 * lane, b = 1.0;
+    for (int r = 0; r < reps; r++) de_run<true>(b, u, 0.999, row, len);
+    long long t3 = wall_clock64();
+    // issue throughput of independent instructions on one wave: 8 streams each
+    double f[8], g8[8]; float h8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { f[q] = 1.0 + 1e-9 * (lane + q); g8[q] = 1.5 + 1e-3 * (lane + q); h8[q] = 1.5f + 1e-3f * (lane + q); }
+    long long t4 = wall_clock64();
+    for (int r = 0; r < 512; r++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) f[q] = __builtin_fma(f[q], 1.0000001, 1e-9);
+    }
+    long long t5 = wall_clock64();
+    for (int r = 0; r < 512; r++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) g8[q] = __builtin_amdgcn_rcp(g8[q]);
+    }
+    long long t6 = wall_clock64();
+    for (int r = 0; r < 512; r++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) h8[q] = __builtin_amdgcn_rcpf(h8[q]);
+    }
+    long long t7 = wall_clock64();
+    double n8[8], d8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { n8[q] = -0.3 - 1e-3 * q; d8[q] = 1.7 + 1e-3 * (lane + q); }
+    for (int r = 0; r < 512; r++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) n8[q] = fdiv_unit(n8[q], d8[q]);
+    }
+    long long t8 = wall_clock64();
+    if (lane == 0 && blockIdx.x == 0) {
+        out[0] = 10.0 * (double)(t1 - t0) / ((double)reps * len); out[1] = 10.0 * (double)(t2 - t1) / ((double)reps * len);
+        out[2] = 10.0 * (double)(t3 - t2) / ((double)reps * (len + 1));
+        out[3] = 10.0 * (double)(t5 - t4) / 4096.0; out[4] = 10.0 * (double)(t6 - t5) / 4096.0; out[5] = 10.0 * (double)(t7 - t6) / 4096.0;
+        out[6] = 10.0 * (double)(t8 - t7) / 4096.0;
+        double acc = a + s + b;
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc += f[q] + g8[q] + (double)h8[q] + n8[q];
+        out[7] = acc;
+    }
+}
+extern "C" int ttx_k_fold_probe(int32_t device, int32_t nblk, int32_t len, double out[7])
+{
+    HIPCHECK(hipSetDevice(device));
+    double *d; HIPCHECK(hipMalloc((void **)&d, 128));
+    double o[8];
+    hipLaunchKernelGGL(k_fold_probe, dim3(nblk), dim3(64), 0, 0, len, 200, d);
+    hipLaunchKernelGGL(k_fold_probe, dim3(nblk), dim3(64), 0, 0, len, 200, d);
+    HIPCHECK(hipMemcpy(o, d, 64, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 7; k++) out[k] = o[k];
+    (void)hipFree(d);
+    return TTX_OK;
+}
+
 extern "C" int ttx_k_latency_probe(int32_t device, double out[5])
 {
     if (!out) return fail(TTX_EINVAL, "ttx_k_latency_probe: null argument");

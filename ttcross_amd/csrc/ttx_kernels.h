@@ -1779,6 +1779,22 @@ __device__ __forceinline__ double de_corner_wave(const DevProb &P, const double 
     return de_finish_vals(P.ising_id, a, m, xv, wv);
 }
 
+// corner entry of the mvn integrand by the first wave of the block (ttx_mvn.h)
+__device__ __forceinline__ double mvn_quadform_wave(int m, const double *dv, int L, double dL, const double *icT, double *tb, int lane);
+__device__ __forceinline__ double mvn_corner_wave(const DevProb &P, const double *par, const short *rowA, int p, int self, const short *rowB,
+                                                  double *scratch, int lane)
+{
+    const int m = P.d;
+    double *dv = scratch, *tb = scratch + ((m + 1) & ~1);
+    for (int x = lane; x < m; x += 64) {
+        const int ix = ((x < p - 1) ? (int)rowA[x] : (x == p - 1) ? self : (int)rowB[x - p]) - 1;
+        dv[x] = par[ix] - P.aux[x];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double ex = mvn_quadform_wave(m, dv, -1, 0.0, P.auxT, tb, lane);
+    return ttx_exp(-0.5 * ex) / P.mvn_norm;
+}
+
 // grow the boundary cores with the neighbours' fibers, evaluate the corner entries, LU-apply
 // blocks [0,NM): "share blocks to the LEFT" receive side (:912-952), one mode index k each;
 // blocks [NM,2NM): "share blocks to the RIGHT" receive side (dmrggmp.f90:598-627), one mode index j each
@@ -1801,6 +1817,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
     double *wscr = lu + 64 * 64 + 4;                      // scratch of the one-element-per-wave evaluator (Ising D/E, P.bnd_wave)
     __shared__ double s_corner;
     const bool dewave = (FUN == FUN_ISING) && P.ising_id != 1 && P.bnd_wave;
+    const bool mvwave = (FUN == FUN_MVN) && P.bnd_wave;
     if ((int)blockIdx.x < P.NM) {
         const int k = blockIdx.x, p = last, br = last + 1;
         if (!P.inR[g] || !upd[br] || k >= P.n[br]) return;
@@ -1816,13 +1833,16 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
             auto dimv = [&](int s) -> short { return (s < p) ? Lt[(size_t)(s - 1) * P.RM + (vp[0] - 1)] : (s == p) ? (short)vp[1] : (s == p + 1) ? (short)(k + 1) : Rt[(size_t)(s - p - 2) * P.RM + snew]; };
             for (int x = tid; x < VSr; x += TTX_BLK) { rowA[x] = (x < p - 1) ? dimv(x + 1) : (short)1; rowB[x] = (x < m - p) ? dimv(p + 1 + x) : (short)1; }
             __syncthreads();
-            if (dewave) {
-                if (tid < 64) { const double c_ = de_corner_wave(P, par, rowA, p, (int)vp[1], rowB, wscr, tid); if (tid == 0) s_corner = c_; }
+            if (dewave || mvwave) {
+                if (tid < 64) {
+                    const double c_ = dewave ? de_corner_wave(P, par, rowA, p, (int)vp[1], rowB, wscr, tid) : mvn_corner_wave(P, par, rowA, p, (int)vp[1], rowB, wscr, tid);
+                    if (tid == 0) s_corner = c_;
+                }
                 __syncthreads();
             }
             if (tid == rrp) {
                 Src3 sx{rowA, p - 1, (int)vp[1], rowB};
-                a = dewave ? s_corner : eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + k);
+                a = (dewave || mvwave) ? s_corner : eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + k);
                 if (!HOST_PASS1(FUN, P)) {
                     atomic_max_pos(&gs.amax, fabs(a));
                     if (k == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n2);   // :936
@@ -1868,13 +1888,16 @@ __global__ __launch_bounds__(TTX_BLK) void k_exch_boundary(DevProb P)
             auto dimv = [&](int s) -> short { return (s < p) ? Lt[(size_t)(s - 1) * P.RM + inew] : (s == p) ? (short)(j + 1) : (s == p + 1) ? (short)vp[2] : Rt[(size_t)(s - p - 2) * P.RM + (vp[3] - 1)]; };
             for (int x = tid; x < VSr; x += TTX_BLK) { rowA[x] = (x < p - 1) ? dimv(x + 1) : (short)1; rowB[x] = (x < m - p) ? dimv(p + 1 + x) : (short)1; }
             __syncthreads();
-            if (dewave) {
-                if (tid < 64) { const double c_ = de_corner_wave(P, par, rowA, p, j + 1, rowB, wscr, tid); if (tid == 0) s_corner = c_; }
+            if (dewave || mvwave) {
+                if (tid < 64) {
+                    const double c_ = dewave ? de_corner_wave(P, par, rowA, p, j + 1, rowB, wscr, tid) : mvn_corner_wave(P, par, rowA, p, j + 1, rowB, wscr, tid);
+                    if (tid == 0) s_corner = c_;
+                }
                 __syncthreads();
             }
             if (tid == rrp) {
                 Src3 sx{rowA, p - 1, j + 1, rowB};
-                y = dewave ? s_corner : eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + P.NM + j);
+                y = (dewave || mvwave) ? s_corner : eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + P.NM + j);
                 if (!HOST_PASS1(FUN, P)) {
                     atomic_max_pos(&gs.amax, fabs(y));
                     if (j == 0) atomicAdd((unsigned long long *)&gs.neval, (unsigned long long)n1);

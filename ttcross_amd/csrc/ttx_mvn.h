@@ -13,42 +13,7 @@
 // per lane.  S is read one row ahead with coalesced loads.  Same operations, same order per lane: bit-identical.
 #pragma once
 #include "ttx_kernels.h"
-
-// s = (..((s + p[0]) + p[1]) ..) + p[len-1], LDS row with wave-uniform address; reads issued one batch ahead
-__device__ __forceinline__ double lds_sum_chain(double s, const double *p, int len)
-{
-    int c = 0;
-    if (len >= 8) {
-        double x[8], y[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) x[q] = p[q];
-        c = 8;
-        for (;;) {
-            if (c + 8 > len) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) s = s + x[q];
-                break;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) y[q] = p[c + q];
-#pragma unroll
-            for (int q = 0; q < 8; q++) s = s + x[q];
-            c += 8;
-            if (c + 8 > len) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) s = s + y[q];
-                break;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) x[q] = p[c + q];
-#pragma unroll
-            for (int q = 0; q < 8; q++) s = s + y[q];
-            c += 8;
-        }
-    }
-    for (; c < len; c++) s = s + p[c];
-    return s;
-}
+#include "ttx_de.h"        // lds_sum_chain
 
 #define MVN_MAXQ 8            // lanes hold ceil(m / 64) <= MVN_MAXQ entries of a row of S: m <= 512
 
