@@ -130,34 +130,42 @@ def cpu_baseline_prefix(argv, limit_s=None):
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_THREADING_LAYER="SEQUENTIAL", OMP_PROC_BIND="close")
     last = None
     try:
-        import pty
         import select
-        mfd, sfd = pty.openpty()          # a terminal, so that the Fortran run time flushes every line
-        p = subprocess.Popen(cmd, stdout=sfd, stderr=subprocess.DEVNULL, env=env)
-        os.close(sfd)
+        # the Fortran run time flushes per line only on a terminal; the GPU boxes have no pty devices, so a preloaded
+        # isatty() shim (oracle/tty_shim.c, bench infrastructure) makes it treat the pipe like one
+        shim = os.path.join(ROOT, "oracle", "tty_shim.so")
+        if not os.path.exists(shim):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "tty_shim.so"], check=False)
+        if os.path.exists(shim):
+            env["LD_PRELOAD"] = shim
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        fd = p.stdout.fileno()
         t0 = time.time()
         buf = ""
-        while time.time() - t0 < limit_s and p.poll() is None:
-            if select.select([mfd], [], [], 0.5)[0]:
-                try:
-                    buf += os.read(mfd, 65536).decode(errors="replace")
-                except OSError:
+        while time.time() - t0 < limit_s:
+            if select.select([fd], [], [], 0.5)[0]:
+                chunk = os.read(fd, 65536)
+                if not chunk:
                     break
+                buf += chunk.decode(errors="replace")
                 *lines, buf = buf.split("\n")
                 for line in lines:
                     mm = re.search(r"time:\s*([0-9.E+-]+)\s+n_evals:\s*(\d+)", line)
                     if mm and float(mm.group(1)) > 0:
                         last = (int(mm.group(2)), float(mm.group(1)), line.split()[0])
+            elif p.poll() is not None:
+                break
         if p.poll() is None:
             p.send_signal(signal.SIGTERM)
             try:
                 p.wait(timeout=10)
             except Exception:  # noqa: BLE001
                 p.kill()
-        os.close(mfd)
-    except Exception:  # noqa: BLE001
+    except Exception as e:  # noqa: BLE001
+        print(f"cpu_baseline_prefix: {type(e).__name__}: {e}", file=sys.stderr)
         return None
     if not last:
+        print("cpu_baseline_prefix: the reference printed no per-sweep line within the limit", file=sys.stderr)
         return None
     return {"value": last[0] / last[1], "unit": "evals/s", "cores": cores, "kind": "reference",
             "sample": f"the first {last[1]:.1f} s of {' '.join(os.path.basename(c) if i == 0 else c for i, c in enumerate(cmd))} (genuine reference, amdflang -O2 -fopenmp + MKL sequential, "
@@ -181,6 +189,7 @@ def bench_utility(a, D, E):
     out_ranks = None
     for it in range(a.warmup + a.steps):
         t = E.TTCross.from_cores(cores)
+        t.tijk([1] * src.d)                 # first utility call allocates the engine's scratch buffers: not part of the step
         t0 = time.perf_counter()
         if op == "ort":
             t.ort()

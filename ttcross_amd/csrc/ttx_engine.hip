@@ -381,7 +381,9 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         h->de_v2 = cfg->pivoting >= 0 && h->de_slots <= TTX_MAXPART && h->lds_de <= 150 * 1024 &&
                    !(getenv("TTX_DE_V2") && atoi(getenv("TTX_DE_V2")) == 0);
         h->lds_de4 = sizeof(double) * de4_lds_doubles(d);
-        h->de_v4 = h->de_v2 && h->lds_de4 <= 150 * 1024 && !(getenv("TTX_DE_V4") && atoi(getenv("TTX_DE_V4")) == 0);
+        // measured and NOT adopted (D_256: k_halfstep_de 4.70 s -> k_halfstep_de4 5.79 s per run): the three dividers each re-read the
+        // node values as LDS broadcasts and meet the folder at a barrier every 36 pairs; opt-in for experiments only
+        h->de_v4 = h->de_v2 && h->lds_de4 <= 150 * 1024 && getenv("TTX_DE_V4") && atoi(getenv("TTX_DE_V4")) == 1;
     }
     if (cfg->fun_id == TTX_FUN_MVN) {
         std::vector<double> t((size_t)d * d);
@@ -1761,8 +1763,16 @@ static int qr(ttx_engine *h, int m, int n, double *A, double *R, double *tau)
 {
     const size_t lds = sizeof(double) * ((size_t)m + n + 4);
     if (lds > 150 * 1024) return fail(TTX_EINVAL, "dtt_ort: unfolding with %d rows does not fit the LDS-staged reflector", m);
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_qr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_qr, dim3(1), dim3(1024), lds, h->stream, m, n, A, R, tau);
+    // small unfoldings are factored entirely inside LDS; larger ones stream the panel from L2 with threads mapped to rows
+    const size_t lds_all = lds + sizeof(double) * (size_t)m * n;
+    static size_t a_q0 = 0, a_q1 = 0;
+    if (lds_all <= 150 * 1024) {
+        if (int rc = ensure_lds(reinterpret_cast<const void *>(k_qr<true>), lds_all, a_q1)) return rc;
+        hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(1024), lds_all, h->stream, m, n, A, R, tau);
+    } else {
+        if (int rc = ensure_lds(reinterpret_cast<const void *>(k_qr<false>), lds, a_q0)) return rc;
+        hipLaunchKernelGGL(k_qr<false>, dim3(1), dim3(1024), lds, h->stream, m, n, A, R, tau);
+    }
     return TTX_OK;
 }
 static int sumsq(ttx_engine *h, size_t n, const double *x, double *out_host)
