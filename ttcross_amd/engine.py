@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libttx.so")
+    """libttx.so of this tree; TTX_LIB names another build of the same sources (e.g. the -DTTX_STAMPS phase-timing build)."""
+    return os.environ.get("TTX_LIB") or os.path.join(_HERE, "lib", "libttx.so")
 
 
 class TTXError(RuntimeError):
