@@ -318,6 +318,20 @@ def main():
         dt = float(t.item())
     value = tt.quad(s["quad"])
     nsweeps = len(tt.sweeps()) - 1
+    # N > 1: the result depends only on the number of bond groups, not on how they are spread over GPUs -- rank 0 repeats
+    # the job as ONE process and the integral must come out bit-identical (the transport between GPUs moved the right bytes)
+    multi_check = None
+    if world > 1 and rank == 0:
+        try:
+            t1 = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
+                           nproc=groups, device=local)
+            t1.run()
+            v1 = t1.quad(s["quad"])
+            multi_check = "integral identical to the single-process run of the same bond groups" if (v1 == value and t1.neval == tt.neval) else \
+                          f"DIFFERS from the single-process run: {value!r} / {tt.neval} vs {v1!r} / {t1.neval}"
+            t1.close()
+        except Exception as e:  # noqa: BLE001
+            multi_check = f"single-process check failed: {e}"
 
     # roofline pass: the same step with every launch bracketed by HIP events on the engine's stream
     tt.set_profile(True)
@@ -384,6 +398,7 @@ def main():
         "value": neval / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (integrand evaluated on the fly; Gauss-Legendre nodes/weights; flang-compatible lottery RNG stream)",
+        "multi_gpu_check": multi_check,
         "config": {"workload": desc, "driver": ("test_crs_ising " + " ".join(str(x) for x in argv[1:])) if argv[0] == "ising" else ("test_crs_mvn " + " ".join(str(x) for x in argv[2:])), "bond_groups": groups, "transport": transport,
                    "neval_per_step": neval // a.steps, "sweeps": nsweeps, "integral": value,
                    "rel_err_vs_analytic": abs(1 - value / s["tru"]) if s["tru"] else None},
