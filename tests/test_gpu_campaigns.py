@@ -74,6 +74,36 @@ def test_fuzz_random_shapes_vs_oracle():
     assert not bad, f"cases that differ from the oracle (kind, m, n, r, piv, groups): {bad}"
 
 
+def test_fuzz_host_callback_vs_oracle():
+    """Random shapes with the integrand evaluated on the HOST (ttx_set_integrand_host) against the oracle with the same C function."""
+    import ctypes
+    ncases = int(os.environ.get("TTX_FUZZ_CASES", "12")) // 2 + 1
+    rng = np.random.default_rng(int(os.environ.get("TTX_FUZZ_SEED", "20261004")) + 2)
+    bdir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    so = os.path.join(bdir, "libuserfun.so")
+    if not os.path.exists(so):
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", os.path.join(ROOT, "tests", "userfun.c"), "-o", so, "-lm"], check=True)
+    lib = ctypes.CDLL(so)
+    addr = ctypes.cast(lib.ttx_test_userfun, ctypes.c_void_p).value
+    bad = []
+    for _ in range(ncases):
+        d = int(rng.integers(2, 12)); n = int(rng.choice([3, 5, 9, 17, 25])); r = int(rng.integers(2, 16)); piv = int(rng.choice([0, 1, 2, 3]))
+        ng = int(rng.integers(1, min(4, d - 1) + 1)) if d > 2 else 1
+        x, w = D.lgwt(n)
+        par = np.concatenate([0.5 * (x + 1.0), 0.5 * w])
+        quad = [par[n:].copy()] * d
+        tt = E.TTCross([n] * d, E.TTX_FUN_HOST, [], r, pivoting=piv, accuracy=500 * D.EPS, quad=quad, nproc=ng)
+        tt.set_integrand_host(addr, par).run()
+        oo = O.dmrgg([n] * d, 4, par, r, piv=piv, accuracy=500 * D.EPS, quad=quad, nproc=ng, user=addr)
+        ok = (np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d]) and [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]] and
+              tt.neval == oo["neval"] and tt.quad(quad) == oo["value"])
+        tt.close()
+        if not ok:
+            bad.append((d, n, r, piv, ng))
+    assert not bad, f"host-callback cases that differ from the oracle (d, n, r, piv, groups): {bad}"
+
+
 def test_soak_repeated_runs_are_identical():
     """The same engine run again and again (cluster kernel: its record tags and barrier counters carry over between
     launches) must return the identical integral and evaluation count every time."""

@@ -16,8 +16,11 @@ program main
  call mvn_init(d,0.d0,1.d0)
  call dtt_dmrgg(tt,integrand,par,maxrank=r,accuracy=acc,pivoting=piv,neval=neval,quad=qq,tru=tru)
  t2=timef()
- write(*,'(a,i12,a,e12.4,a)') '...with',neval,' evaluations completed in ',t2-t1,' sec.'
- val=dtt_quad(tt,qq)
+ if(me.eq.0)write(*,'(a,i12,a,e12.4,a)') '...with',neval,' evaluations completed in ',t2-t1,' sec.'
+ val=dtt_quad(tt,qq)                          ! collective; the report is rank 0's
+ if(me.ne.0)then
+  call dealloc(tt); call mpi_finalize(info); stop
+ end if
  write(*,'(a,e50.40)') 'computed value:',val
  write(*,'(a,e50.40)') 'analytic value:',tru
  write(*,'(a,f7.2)') 'correct digits:',-dlog(dabs(1.d0-val/tru))/dlog(10.d0)
