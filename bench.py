@@ -222,6 +222,81 @@ def tt_own(nproc, d):
     return [first + int(float(last - first + 1) * p / nproc) for p in range(nproc)] + [last + 1]
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def supervise(a, rank, world):
+    """N > 1: every rank started by torch.distributed.run becomes a SUPERVISOR that never touches the GPU and runs the
+    measurement in a child process (`--child`), one attempt per transport: first the in-library RCCL transport, then the
+    host-staged gloo transport (the one the multi-process tests cover).  An attempt whose child crashes or does not finish
+    within --attempt-timeout on ANY rank is stopped on all ranks (the supervisors talk over their own gloo group / store)
+    and the next transport is tried, so that a fault in the RCCL path costs one time-out, not the bench line.
+    The child does the barrier + synchronize bracketing and the max over ranks itself; rank 0's JSON line is relayed."""
+    import signal
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    store = dist.distributed_c10d._get_default_store()
+    attempts = ["gloo"] if a.backend == "gloo" else ["nccl", "gloo"]
+    log = []
+    for k, backend in enumerate(attempts):
+        port = [_free_port() if rank == 0 else 0]
+        dist.broadcast_object_list(port, src=0)
+        # the children rendezvous among themselves on a fresh port; without the launcher's TORCHELASTIC_* variables
+        # (TORCHELASTIC_USE_AGENT_STORE would make them look for the launcher's store on that port)
+        env = {k_: v for k_, v in os.environ.items() if not k_.startswith("TORCHELASTIC_")}
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
+        argv = [x for x in sys.argv[1:]]
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--child", "--backend", backend, "--attempt", str(k)]
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        key = f"bench_attempt_{k}_failed"
+        t0 = time.time()
+        why = None
+        while child.poll() is None:
+            time.sleep(0.5)
+            if time.time() - t0 > a.attempt_timeout:
+                why = f"no result within {a.attempt_timeout:.0f} s"
+            elif store.check([key]):
+                why = "stopped: the attempt failed on another rank"
+            if why:
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)        # exactly the process group started above
+                except ProcessLookupError:
+                    pass
+                child.wait()
+                break
+        out = child.stdout.read() if child.stdout else ""
+        line = None
+        for ln in out.splitlines():
+            if ln.startswith("{"):
+                line = ln
+        bad = why is not None or child.returncode != 0 or (rank == 0 and line is None)
+        if bad:
+            store.set(key, "1")
+            if why is None:
+                why = f"child exit code {child.returncode}" if child.returncode != 0 else "child printed no result line"
+            print(f"[bench supervisor, rank {rank}] attempt {k} ({backend}): {why}", file=sys.stderr, flush=True)
+        flag = [1 if bad else 0]
+        allflags = [None] * world
+        dist.all_gather_object(allflags, flag)
+        failed = [i for i, f in enumerate(allflags) if f[0]]
+        log.append({"backend": backend, "ok": not failed, "failed_ranks": failed, "seconds": round(time.time() - t0, 1)})
+        if not failed:
+            if rank == 0:
+                res = json.loads(line)
+                res["attempts"] = log
+                print(json.dumps(res), flush=True)
+            dist.destroy_process_group()
+            return 0
+    dist.destroy_process_group()
+    if rank == 0:
+        print(f"[bench supervisor] every transport failed: {log}", file=sys.stderr, flush=True)
+    return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,6 +307,9 @@ def main():
     ap.add_argument("--groups", type=int, default=0, help="bond groups = MPI ranks of the reference's domain split; default 8 (config 3 of BASELINE.json) at every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (gloo: rehearsal with several ranks on one GPU)")
+    ap.add_argument("--attempt-timeout", type=float, default=420.0, help="N>1: seconds one transport attempt may take before the supervisors stop it")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)        # set by supervise(): this process does the measurement
+    ap.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -240,6 +318,24 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world > 1 and not a.child and a.workload not in UTIL_WORKLOADS:
+        raise SystemExit(supervise(a, rank, world))
+    if a.child and os.environ.get("TTX_BENCH_TEST_FAULT"):       # tests/test_dist_cpu.py: "<attempt>:<rank>:hang|crash|dry"
+        for spec in os.environ["TTX_BENCH_TEST_FAULT"].split(","):
+            att, rk, what = spec.split(":")
+            if (att == "*" or int(att) == a.attempt) and (rk == "*" or int(rk) == rank):
+                if what == "hang":
+                    time.sleep(3600)
+                if what == "crash":
+                    raise SystemExit(7)
+                if what == "dry":       # no engine: checks the supervisors' protocol only
+                    import torch.distributed as dist
+                    dist.init_process_group("gloo")
+                    dist.barrier()
+                    if rank == 0:
+                        print(json.dumps({"metric": "dry", "value": 1.0, "n_gpus": world, "backend": a.backend}))
+                    dist.destroy_process_group()
+                    return
     dist = None
     if world > 1:
         import torch
