@@ -78,6 +78,7 @@ struct WStream {
     __device__ __forceinline__ double ld(int b, int lane) const { const int ix = b * 64 + lane; return ix < total ? g[ix] : 1.0; }
     __device__ __forceinline__ void init(const double *g_, int total_, double *buf_, int lane)
     { g = g_; total = total_; buf = buf_; rA = ld(0, lane); rB = ld(1, lane); nextb = 2; avail = 0; rd = 0; }
+    // two batches in flight (four measured no faster: D_256 half-steps 4.17 vs 4.20 s)
     __device__ __forceinline__ void refill(int lane)
     {
         __builtin_amdgcn_wave_barrier();
@@ -97,22 +98,36 @@ struct WStream {
     }
 };
 
-// the bond-spanning tail of a row: pair with s2 (x2), then with the right dims xr[0..B) (LDS, wave-uniform)
+// the bond-spanning tail of a row: pair with s2 (x2), then with the right dims xr[0..B) (LDS, wave-uniform), eight pairs
+// at a time: running products, the eight divisions stage by stage (de_t2xw), then the factors into `a` in order
 template <bool FAST>
 __device__ __forceinline__ void de_run(double &a, double u, double x2, const double *xr, int B)
 {
     u = u * x2; a = a * de_t2<FAST>(u);
     int j = 0;
-    if (B >= 4) {
-        double y0 = xr[0], y1 = xr[1], y2 = xr[2], y3 = xr[3];
-        for (; j + 4 <= B; j += 4) {                   // four independent divisions in flight; products in order
-            const double x0 = y0, x1_ = y1, x2_ = y2, x3 = y3;
-            if (j + 8 <= B) { y0 = xr[j + 4]; y1 = xr[j + 5]; y2 = xr[j + 6]; y3 = xr[j + 7]; }    // next batch's LDS reads fly under the divisions
-            const double u1 = u * x0, u2 = u1 * x1_, u3 = u2 * x2_, u4 = u3 * x3;
-            const double t1 = de_t2<FAST>(u1), t2 = de_t2<FAST>(u2), t3 = de_t2<FAST>(u3), t4 = de_t2<FAST>(u4);
-            a = a * t1; a = a * t2; a = a * t3; a = a * t4;
-            u = u4;
+    if (B >= 8) {
+        double y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = xr[k];
+        for (; j + 8 <= B; j += 8) {
+            double uu[8], t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { u = u * y[k]; uu[k] = u; }
+            if (j + 16 <= B) {                          // next batch's LDS reads fly under the divisions
+#pragma unroll
+                for (int k = 0; k < 8; k++) y[k] = xr[j + 8 + k];
+            }
+            de_t2xw<FAST, 8>(uu, t);
+#pragma unroll
+            for (int k = 0; k < 8; k++) a = a * t[k];
         }
+    }
+    if (j + 4 <= B) {
+        const double u1 = u * xr[j], u2 = u1 * xr[j + 1], u3 = u2 * xr[j + 2], u4 = u3 * xr[j + 3];
+        double t1, t2, t3, t4;
+        de_t2x4<FAST>(u1, u2, u3, u4, t1, t2, t3, t4);
+        a = a * t1; a = a * t2; a = a * t3; a = a * t4;
+        u = u4; j += 4;
     }
     for (; j < B; j++) { u = u * xr[j]; a = a * de_t2<FAST>(u); }
 }
@@ -305,7 +320,7 @@ __device__ __forceinline__ double de_elem_tab(int m, int A, const double *xv, co
             int j = 0;
             for (; j + 4 <= B; j += 4) {
                 const double u1 = u * xr[j], u2 = u1 * xr[j + 1], u3 = u2 * xr[j + 2], u4 = u3 * xr[j + 3];
-                row[2 + j] = de_t2<FAST>(u1); row[3 + j] = de_t2<FAST>(u2); row[4 + j] = de_t2<FAST>(u3); row[5 + j] = de_t2<FAST>(u4);
+                de_t2x4<FAST>(u1, u2, u3, u4, row[2 + j], row[3 + j], row[4 + j], row[5 + j]);
                 u = u4;
             }
             for (; j < B; j++) { u = u * xr[j]; row[2 + j] = de_t2<FAST>(u); }
@@ -519,4 +534,404 @@ __global__ __launch_bounds__(256) void k_halfstep_de4(DevProb P, int h, int dir,
         wave_argmax(ab, bb, bi);
         if (lane == 0) { Partial pr; pr.absmax = ab; pr.val = bb; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][w] = pr; }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_halfstep_de5: the half-step of ONE (pivot, mode-chunk) by a RELAY of four waves (round 2; measured unit costs in
+// profiles/r02_probe_dpp.txt).  A bond-spanning pair costs 42 ns of a lone wave but only ~30-36 ns of a SIMD's issue slots,
+// and a launch of k_halfstep_de has at most r x ceil(n/64) x groups waves -- 624 at D_256, fewer than the chip's 1024 SIMDs.
+// So the body of every row of the pair triangle (the B right dims) is cut into four contiguous segments, one per wave
+// (lane = mode index in every wave).  A wave
+//   * runs the cheap running product u of the row up to its segment (one multiply per pair, LDS broadcasts),
+//   * performs the divisions of its own segment, four at a time, keeping the factors ((u-1)/(u+1))^2 in REGISTERS,
+//   * then waits for the token -- the running product `a` of the element, 64 lanes x 8 bytes in an LDS mailbox --,
+//     multiplies its factors in, in order, and hands the token to the next wave (the last one to wave 0: next row).
+// Wave 0 additionally owns the head of a row (the tabulated factors TL, the pairs with dims p and p+1), the tabulated
+// tail TR, the b-part, the weights, the residual and the arg-max record.  While the token travels, every wave is already
+// dividing for the next row, so a row lasts as long as one wave needs for a QUARTER of its divisions; nothing but the
+// token crosses waves (no tile traffic, no workgroup barrier).  Every product is still taken by one lane in the
+// reference's order: bit-identical to k_halfstep_de and the oracle.
+// Mailboxes: a slot is either the sentinel (a NaN pattern no arithmetic produces) or a value; the receiver polls its
+// own slot, takes the value and restores the sentinel before it sends on -- LDS operations of one wave complete in order
+// and the next value for this slot can only be produced after the token has passed through the receiver again.
+// Every wait is bounded (a fault would show as a wrong result in the tests, not as a hung GPU).
+// ------------------------------------------------------------------------------------------------------------------
+#define DE5_W 4
+#define DE5_SEG 64               // most body factors per wave and row (B <= 256)
+#define DE5_SENT 0xfff85a5a00000001ull
+__host__ __device__ inline size_t de5_lds_doubles(int m) { const int VS = ((m + 7) & ~7) + 24; return (size_t)5 * VS + 128 + (size_t)DE5_W * 64; }
+__host__ __device__ inline bool de5_fits(int m) { return m - 2 <= DE5_W * DE5_SEG; }
+
+__device__ __forceinline__ void de5_send(unsigned long long *box, int lane, double a)
+{
+    __hip_atomic_store(&box[lane], (unsigned long long)__double_as_longlong(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// false: the token did not come (bounded wait) or another wave of the workgroup gave up -- the caller leaves the kernel
+__device__ __forceinline__ bool de5_recv(unsigned long long *box, int lane, double &a, int *giveup)
+{
+    unsigned long long v; unsigned spins = 0;
+    for (;;) {
+        v = __hip_atomic_load(&box[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!__any(v == DE5_SENT)) break;
+        if (++spins > (1u << 20) || ((spins & 255u) == 0 && __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+            __hip_atomic_store(giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(&box[lane], DE5_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    a = __longlong_as_double((long long)v);
+    return true;
+}
+// a relay that broke: stop the run after this sweep (ctl[0]) and tell the host (ctl[3]); ttx_run then repeats the run
+// with k_halfstep_de
+#define DE5_FAIL() do { if (lane == 0) { atomicAdd(&P.ctl[3], 1); P.ctl[0] = 1; } return; } while (0)
+
+template <bool FAST>
+__global__ __launch_bounds__(64 * DE5_W, 2) void k_halfstep_de5(DevProb P, int h, int dir, int mode)
+{
+    extern __shared__ __align__(16) double dyn[];
+    __shared__ StepState cur;
+    __shared__ int giveup;
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = P.d;
+    GroupState &gs = P.gs[g];
+    if (tid == 0) { cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]); giveup = 0; }
+    __syncthreads();
+    if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
+    const bool iscol = (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
+    const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
+    const int nf = iscol ? r0 * n1 : n2 * r2;
+    const int nv = iscol ? r0 : r2, nm = iscol ? n1 : n2, nch = (nm + 63) >> 6;
+    const int npart = nv * nch;
+    const int w = blockIdx.x;
+    const int crs = cur.crs + 1;
+    const int havecol = cur.havecol | (iscol ? 1 : 0), haverow = cur.haverow | (iscol ? 0 : 1);
+    const int done = (mode == 1 || mode == 2) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
+    const bool resid = (mode == 0) && !done;
+    if (w == 0 && tid == 0) {
+        StepState nx = cur;
+        nx.crs = crs; nx.havecol = havecol; nx.haverow = haverow; nx.done = done;
+        nx.pending = resid ? (iscol ? 1 : 2) : 0;
+        nx.npart = npart;
+        gs.S[h + 1] = nx;
+        if (mode != 2) gs.neval += nf;                                        // :527 / :560 / :509
+        gs.bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
+        gs.n_resid += resid ? 1 : 0;
+    }
+    if (w >= npart) return;
+    const int pv = w / nch, vmode = (w - pv * nch) * 64 + lane;
+    const bool live = vmode < nm;
+    const int A = p - 1, B = m - p - 1;
+    const int pl = iscol ? pv : cur.ii - 1, qr = iscol ? cur.qq - 1 : pv;
+    const int n1m = P.n[1];
+    const double *nodes = P.par, *weights = P.par + n1m;
+    const int VS = ((m + 7) & ~7) + 24;
+    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *xr = wl + VS, *wr = xr + VS, *ringL = wr + VS, *ringR = ringL + 64;
+    unsigned long long *box = reinterpret_cast<unsigned long long *>(ringR + 64);          // [DE5_W][64]
+    const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
+    const double *TLg = P.deTL + (size_t)g * tsz + (size_t)pl * NP, *TRg = P.deTR + (size_t)g * tsz + (size_t)qr * NP;
+    const double *ULg = P.deUL + ((size_t)g * P.RM + pl) * (m + 1);
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    for (int x = tid; x < A; x += 64 * DE5_W) { const int ix = Lt[(size_t)x * P.RM + pl] - 1; xl[x] = nodes[ix]; wl[x] = weights[ix]; }
+    for (int x = tid; x < B; x += 64 * DE5_W) { const int ix = Rt[(size_t)x * P.RM + qr] - 1; xr[x] = nodes[ix]; wr[x] = weights[ix]; }
+    for (int x = B + tid; x < B + 16; x += 64 * DE5_W) xr[x] = 1.0;            // the division batches of four may run past B
+    for (int x = tid; x <= A; x += 64 * DE5_W) UL[x] = ULg[x];
+    box[tid] = DE5_SENT;
+    const int i1 = iscol ? (live ? vmode : 0) : cur.jj - 1, i2 = iscol ? cur.kk - 1 : (live ? vmode : 0);
+    const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
+    __syncthreads();
+    // segments of the body xr[0..B): SEG per wave (a multiple of 4), nact waves have work
+    const int SEG = (((B + DE5_W - 1) / DE5_W) + 3) & ~3;
+    const int nact = (B > 0) ? (B + SEG - 1) / SEG : 1;
+    if (wv >= nact) return;                                   // no barrier below this line
+    const int jlo = wv * SEG, cnt = (B > 0) ? min(SEG, B - jlo) : 0;
+    unsigned long long *mybox = box + (size_t)wv * 64, *nextbox = box + (size_t)((wv + 1 == nact) ? 0 : wv + 1) * 64;
+    double a = 1.0;
+    WStream sl, sr;
+    if (wv == 0) { sl.init(TLg, A * (A + 1) / 2, ringL, lane); sr.init(TRg, B * (B + 1) / 2, ringR, lane); }
+    for (int i = 0; i <= A + 1; i++) {
+        const bool hasx1 = (i <= A);
+        const double uh = hasx1 ? UL[i] * x1 : 1.0;
+        const double u2 = uh * x2;
+        double u = u2;
+        if (jlo > 0) u = lds_chain(u, xr, jlo);              // the row's running product up to my segment
+        double f[DE5_SEG];
+#pragma unroll
+        for (int kc = 0; kc < DE5_SEG / 4; kc++) {
+            if (4 * kc < cnt) {                               // wave-uniform
+                const double *xp = xr + jlo + 4 * kc;
+                const double ua = u * xp[0], ub = ua * xp[1], uc = ub * xp[2], ud = uc * xp[3];
+                f[4 * kc] = de_t2<FAST>(ua); f[4 * kc + 1] = de_t2<FAST>(ub); f[4 * kc + 2] = de_t2<FAST>(uc); f[4 * kc + 3] = de_t2<FAST>(ud);
+                u = ud;
+            }
+        }
+        if (wv == 0) {
+            const double t1 = hasx1 ? de_t2<FAST>(uh) : 1.0, t2 = de_t2<FAST>(u2);
+            if (i > 0 && nact > 1 && !de5_recv(mybox, lane, a, &giveup)) DE5_FAIL();
+            if (hasx1) { a = sl.chain(a, A - i, lane); a = a * t1; }
+            a = a * t2;
+        } else if (!de5_recv(mybox, lane, a, &giveup)) DE5_FAIL();
+#pragma unroll
+        for (int kc = 0; kc < DE5_SEG / 4; kc++) {
+            if (4 * kc + 4 <= cnt) { a = a * f[4 * kc]; a = a * f[4 * kc + 1]; a = a * f[4 * kc + 2]; a = a * f[4 * kc + 3]; }
+            else if (4 * kc < cnt) {
+                const int rem = cnt - 4 * kc;
+                a = a * f[4 * kc];
+                if (rem > 1) a = a * f[4 * kc + 1];
+                if (rem > 2) a = a * f[4 * kc + 2];
+            }
+        }
+        if (nact > 1) de5_send(nextbox, lane, a);
+    }
+    if (wv != 0) return;
+    if (nact > 1 && !de5_recv(mybox, lane, a, &giveup)) DE5_FAIL();
+    a = sr.chain(a, B * (B + 1) / 2, lane);
+    // ---- b-part (id 2) and the weights (:197-218), order of de_finish ----
+    const int id = P.ising_id;
+    double b = 0.0;
+    if (id == 2) {
+        double v = 1.0, ww = 1.0, vk = 1.0, wk = 1.0;
+        for (int j = B - 1; j >= 0; j--) { vk = vk * xr[j]; v = v + vk; }
+        vk = vk * x2; v = v + vk;
+        vk = vk * x1; v = v + vk;
+        for (int j = A - 1; j >= 0; j--) { vk = vk * xl[j]; v = v + vk; }
+        for (int j = 0; j < A; j++) { wk = wk * xl[j]; ww = ww + wk; }
+        wk = wk * x1; ww = ww + wk;
+        wk = wk * x2; ww = ww + wk;
+        for (int j = 0; j < B; j++) { wk = wk * xr[j]; ww = ww + wk; }
+        b = 1.0 / (v * ww);
+    }
+    double fv = (id == 2) ? 2 * a * b : 2 * a;
+    for (int j = 0; j < A; j++) fv = fv * wl[j];
+    fv = fv * w1; fv = fv * w2;
+    for (int j = 0; j < B; j++) fv = fv * wr[j];
+    a = fv;
+    const int u_ = iscol ? pv : vmode, v_ = iscol ? vmode : pv;
+    const int t = iscol ? (u_ + r0 * v_) : (u_ + n2 * v_);
+    if (live) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
+    const double mx = wave_max(live ? fabs(a) : 0.0);
+    if (lane == 0 && mode != 1) atomic_max_pos(&gs.amax, mx);
+    if (resid) {
+        const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+        double bb = a, ab = -1.0; int bi = INT_MAX;
+        if (live) {
+            if (iscol) {
+                const double *c = Cp + u_ + (size_t)P.RM * v_;
+                const double *xq = Wq + (cur.kk - 1) + (size_t)P.NM * (cur.qq - 1);
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) bb = bb + (-xq[P.SW * s]) * c[P.SS * s];
+            } else {
+                const double *wvp = Wq + u_ + (size_t)P.NM * v_;
+                const double *xc = Cp + (cur.ii - 1) + (size_t)P.RM * (cur.jj - 1);
+                double tt = 0.0;
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) tt = tt + wvp[P.SW * s] * xc[P.SS * s];
+                bb = bb + (-1.0) * tt;
+            }
+            ab = fabs(bb); bi = t;
+        }
+        wave_argmax(ab, bb, bi);
+        if (lane == 0) { Partial pr; pr.absmax = ab; pr.val = bb; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][w] = pr; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_lottery_eval_de_rows: FOUR lottery candidates per wave, one per DPP row of 16 lanes (round 2).
+// With one candidate per wave (k_lottery_eval_de) the 32 640 ordered multiplies of an element were LDS broadcasts done
+// identically by all 64 lanes (5.8-8 ns per factor and wave), and only 16 lanes divided.  All candidates of a group
+// sit at the same bond, so their pair triangles have the same shape and four of them can share a wave's control flow:
+//   * lane n of a row holds ONE factor of a chunk of 16 (32 for the tabulated streams) consecutive factors;
+//     `a = a * factor` takes the factor of lane k by a DPP row broadcast (v_mov_b64_dpp row_newbcast:k + v_mul_f64:
+//     4.5 ns per factor for the four candidates together, profiles/r02_probe_dpp.txt), no LDS traffic;
+//   * bond-spanning pairs: lane n owns column c0+n of the row of the triangle: it advances its own running product u by the
+//     16 node values between two chunks (per-lane LDS reads, conflict-free) and divides once per chunk -- all 64 lanes
+//     divide; the advance of chunk c+1, the division of chunk c and the ordered multiplies of chunk c-1 are independent
+//     instruction streams in one loop body;
+//   * tabulated factors TL / TR: lane n loads factors 2n, 2n+1 of a 32-factor chunk of ITS candidate's table row, four chunks
+//     ahead.
+// The order of all products is that of de_elem_tab, the operations per factor those of de_t2: bit-identical.
+// ------------------------------------------------------------------------------------------------------------------
+template <int K> __device__ __forceinline__ double rowbc(double f)
+{
+    return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(f), 0x150 + K, 0xf, 0xf, false));
+}
+#define TTX_RB16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+// a = a * (factor of lane off) * ... * (factor of lane off+c-1) of every DPP row; off, c wave-uniform
+__device__ __forceinline__ double row_fold16(double a, double f, int off, int c)
+{
+    if (off == 0 && c == 16) {
+#define TTX_RB_ALL(k) a = a * rowbc<k>(f);
+        TTX_RB16(TTX_RB_ALL)
+#undef TTX_RB_ALL
+    } else {
+#define TTX_RB_SOME(k) if (k >= off && k < off + c) a = a * rowbc<k>(f);
+        TTX_RB16(TTX_RB_SOME)
+#undef TTX_RB_SOME
+    }
+    return a;
+}
+// the same over a chunk of 32 factors held as (lo, hi) = factors (2 lane, 2 lane + 1)
+__device__ __forceinline__ double row_fold32(double a, double lo, double hi, int off, int c)
+{
+    if (off == 0 && c == 32) {
+#define TTX_RB_ALL(k) a = a * rowbc<k>(lo); a = a * rowbc<k>(hi);
+        TTX_RB16(TTX_RB_ALL)
+#undef TTX_RB_ALL
+    } else {
+#define TTX_RB_SOME(k) if (2 * k >= off && 2 * k < off + c) a = a * rowbc<k>(lo); if (2 * k + 1 >= off && 2 * k + 1 < off + c) a = a * rowbc<k>(hi);
+        TTX_RB16(TTX_RB_SOME)
+#undef TTX_RB_SOME
+    }
+    return a;
+}
+// per-DPP-row stream of tabulated factors g[0..total): every row has its own g, all rows the same total and the same takes
+struct RStream {
+    const double *g; int total, nextc, off; double lo0, hi0, lo1, hi1, lo2, hi2, lo3, hi3;
+    __device__ __forceinline__ void ld(int c, int n, double &lo, double &hi) const
+    {
+        const int ix = 32 * c + 2 * n;
+        lo = ix < total ? g[ix] : 1.0; hi = ix + 1 < total ? g[ix + 1] : 1.0;
+    }
+    __device__ __forceinline__ void init(const double *g_, int total_, int n)
+    { g = g_; total = total_; ld(0, n, lo0, hi0); ld(1, n, lo1, hi1); ld(2, n, lo2, hi2); ld(3, n, lo3, hi3); nextc = 4; off = 0; }
+    __device__ __forceinline__ double take(double a, int cnt, int n)
+    {
+        while (cnt > 0) {
+            if (off == 32) { lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = lo3; hi2 = hi3; ld(nextc, n, lo3, hi3); nextc++; off = 0; }
+            const int c = cnt < 32 - off ? cnt : 32 - off;
+            a = row_fold32(a, lo0, hi0, off, c);
+            off += c; cnt -= c;
+        }
+        return a;
+    }
+};
+// LDS per DPP row: xv | wv | UL, each RSW doubles; RSW = 16 mod 32 so that the four rows' 16-lane reads hit disjoint bank halves
+__host__ __device__ inline int de_rows_stride(int m) { int s = m + 56; return ((s + 31) & ~31) + 16; }
+__host__ __device__ inline size_t de_rows_lds_doubles(int m) { return (size_t)12 * de_rows_stride(m); }
+
+// One row of the pair triangle for the four candidates of a wave: a = a * t(u0 xs[0]) * t(u0 xs[0] xs[1]) * ... (L factors,
+// t(u) = ((u-1)/(u+1))^2); `neutral0`: the first column is the neutral 1.0 (the row that starts after dim p).
+// xs is this DPP row's array of node values, readable (as 1.0) up to 47 entries past L.
+template <bool FAST>
+__device__ __forceinline__ double rows_span(double a, double u0, const double *xs, int L, bool neutral0, int n)
+{
+    const int nchunk = (L + 15) >> 4, cntlast = L - 16 * (nchunk - 1);
+    // column n of chunk 0: u = u0 * xs[0] * .. * xs[n]
+    double u = u0;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const double x = (s == 0 && neutral0) ? 1.0 : xs[s];
+        u = u * ((s <= n) ? x : 1.0);
+    }
+    // steady state per chunk c: three independent chains -- the advance of u to chunk c+1 (16 multiplies by node values
+    // read one chunk ahead), the division of chunk c, the ordered multiplies of chunk c-1 -- written INTERLEAVED,
+    // statement by statement (the compiler otherwise emits them one after the other, every LDS latency exposed)
+    double xq[16], xn[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) xq[s] = xs[n + 1 + s];
+    double unx = u;
+#pragma unroll
+    for (int s = 0; s < 16; s++) unx = unx * xq[s];
+#pragma unroll
+    for (int s = 0; s < 16; s++) xq[s] = xs[16 + n + 1 + s];                 // node values for the advance to chunk 2
+    double tprev = de_t2<FAST>(u);
+    if (neutral0 && n == 0) tprev = 1.0;
+    // one chunk: advance with the node values in `xc`, fetch those of the chunk after into `xf` (the two arrays swap
+    // roles from chunk to chunk: no register copies)
+    auto chunk = [&](const double (&xc)[16], double (&xf)[16], int c) {
+        u = unx;
+        const double *xa = xs + 16 * (c + 1) + n + 1;
+#pragma unroll
+        for (int s = 0; s < 16; s++) xf[s] = xa[s];                          // one chunk ahead: in flight under this chunk's work
+        double tcur;
+        if (FAST) {
+            const double nn = u - 1.0, dd = u + 1.0;
+            a = a * rowbc<0>(tprev);   unx = unx * xc[0];
+            double r = __builtin_amdgcn_rcp(dd);
+            a = a * rowbc<1>(tprev);   unx = unx * xc[1];
+            double e = __builtin_fma(-dd, r, 1.0);
+            a = a * rowbc<2>(tprev);   unx = unx * xc[2];
+            r = __builtin_fma(r, e, r);
+            a = a * rowbc<3>(tprev);   unx = unx * xc[3];
+            e = __builtin_fma(-dd, r, 1.0);
+            a = a * rowbc<4>(tprev);   unx = unx * xc[4];
+            r = __builtin_fma(r, e, r);
+            a = a * rowbc<5>(tprev);   unx = unx * xc[5];
+            const double q = nn * r;
+            a = a * rowbc<6>(tprev);   unx = unx * xc[6];
+            const double rem = __builtin_fma(-dd, q, nn);
+            a = a * rowbc<7>(tprev);   unx = unx * xc[7];
+            const double sq = __builtin_fma(rem, r, q);
+            a = a * rowbc<8>(tprev);   unx = unx * xc[8];
+            tcur = sq * sq;
+            a = a * rowbc<9>(tprev);   unx = unx * xc[9];
+            a = a * rowbc<10>(tprev);  unx = unx * xc[10];
+            a = a * rowbc<11>(tprev);  unx = unx * xc[11];
+            a = a * rowbc<12>(tprev);  unx = unx * xc[12];
+            a = a * rowbc<13>(tprev);  unx = unx * xc[13];
+            a = a * rowbc<14>(tprev);  unx = unx * xc[14];
+            a = a * rowbc<15>(tprev);  unx = unx * xc[15];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; s++) unx = unx * xc[s];
+            tcur = de_t2<false>(u);
+            a = row_fold16(a, tprev, 0, 16);
+        }
+        tprev = tcur;
+    };
+    int c = 1;
+    for (; c + 1 < nchunk; c += 2) { chunk(xq, xn, c); chunk(xn, xq, c + 1); }
+    if (c < nchunk) chunk(xq, xn, c);
+    return row_fold16(a, tprev, 0, cntlast);
+}
+
+// TAB: tabulated factors of the pivots (k_de_tables) for the pairs on one side of the bond, divisions only for the spanning
+// pairs; !TAB: every pair by division.  Measured at D_256: the table rows of the ~330 candidates of a group are 0.5 MB each
+// and come from HBM (1.4 GB per launch, latency-bound at 1.5 TB/s: 909 us per launch), while a division costs this kernel
+// 13.5 instructions per 16 factors of four candidates -- so the lottery divides everything and reads no tables.
+template <bool FAST, bool TAB>
+__global__ __launch_bounds__(64) void k_lottery_eval_de_rows(DevProb P)
+{
+    extern __shared__ __align__(16) double dyn[];
+    const int g = blockIdx.y, lane = threadIdx.x, row = lane >> 4, n = lane & 15, m = P.d;
+    const GroupState &gs = P.gs[g];
+    const StepState &st = gs.S[0];
+    if (!st.active) return;
+    const int p = st.p, first = gs.first;
+    const int nlot = st.r0 + st.n1 + st.n2 + st.r2;
+    if (4 * (int)blockIdx.x >= nlot) return;
+    const int il_raw = 4 * blockIdx.x + row, il = il_raw < nlot ? il_raw : nlot - 1;   // a row past the end repeats the last candidate
+    const int *cand = P.lotc + ((size_t)g * P.lot_max + il) * 4;
+    const int ci = cand[0] - 1, cj = cand[1] - 1, ck = cand[2] - 1, cq = cand[3] - 1;
+    const int A = p - 1, B = m - p - 1, RSW = de_rows_stride(m), n1m = P.n[1];
+    double *xv = dyn + (size_t)row * 3 * RSW, *wv = xv + RSW, *UL = wv + RSW;
+    const double *nodes = P.par, *weights = P.par + n1m;
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    for (int x = n; x < m; x += 16) {
+        const int ix = (x < A) ? Lt[(size_t)x * P.RM + ci] - 1 : (x == A) ? cj : (x == A + 1) ? ck : Rt[(size_t)(x - A - 2) * P.RM + cq] - 1;
+        xv[x] = nodes[ix]; wv[x] = weights[ix];
+    }
+    for (int x = m + n; x < m + 56; x += 16) xv[x] = 1.0;          // the advance of u runs up to 47 columns past a row's end
+    double a = 1.0;
+    if (TAB) {
+        const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
+        const double *ULg = P.deUL + ((size_t)g * P.RM + ci) * (m + 1);
+        for (int x = n; x <= A; x += 16) UL[x] = ULg[x];
+        RStream sl, sr;
+        sl.init(P.deTL + (size_t)g * tsz + (size_t)ci * NP, A * (A + 1) / 2, n);
+        sr.init(P.deTR + (size_t)g * tsz + (size_t)cq * NP, B * (B + 1) / 2, n);
+        __syncthreads();
+        // xs[c]: node of column c of a spanning row: c = 0 dim p, c = 1 dim p+1, c >= 2 right dims; 1.0 past the end
+        for (int i = 0; i <= A + 1; i++) {
+            const bool hasx1 = (i <= A);
+            if (hasx1) a = sl.take(a, A - i, n);
+            a = rows_span<FAST>(a, hasx1 ? UL[i] : 1.0, xv + A, B + 2, !hasx1, n);
+        }
+        a = sr.take(a, B * (B + 1) / 2, n);
+    } else {
+        __syncthreads();
+        for (int i = 0; i < m; i++) a = rows_span<FAST>(a, 1.0, xv + i, m - i, false, n);     // row i: pairs with dims i+1 .. m
+    }
+    const double f = de_finish_vals(P.ising_id, a, m, xv, wv);
+    if (n == 0 && il_raw < nlot) P.lotf[(size_t)g * P.lot_max + il] = f;
 }

@@ -136,7 +136,10 @@ struct ttx_engine {
     int half_vals = 0, lot_vals = 0;
     int de_v2 = 0;                      // Ising D/E: wave-per-pivot half-step kernel k_halfstep_de (ttx_de.h)
     int de_v4 = 0; size_t lds_de4 = 0;  // ... with three divider waves beside the folder wave (k_halfstep_de4)
+    int de_v5 = 0; size_t lds_de5 = 0;  // ... as a relay of four waves (k_halfstep_de5): the default where it fits
+    int de5_fallbacks = 0;
     int de_slots = 0; size_t lds_de = 0;
+    int lot_rows = 0; size_t lds_der = 0;   // ... four candidates per wave, one per DPP row (k_lottery_eval_de_rows)
     int lot_wave = 0; size_t lds_dew = 0;   // Ising D/E: lottery candidates and boundary corners one element per wave (ttx_de.h)
     int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
@@ -384,6 +387,8 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         // measured and NOT adopted (D_256: k_halfstep_de 4.70 s -> k_halfstep_de4 5.79 s per run): the three dividers each re-read the
         // node values as LDS broadcasts and meet the folder at a barrier every 36 pairs; opt-in for experiments only
         h->de_v4 = h->de_v2 && h->lds_de4 <= 150 * 1024 && getenv("TTX_DE_V4") && atoi(getenv("TTX_DE_V4")) == 1;
+        h->lds_de5 = sizeof(double) * de5_lds_doubles(d);
+        h->de_v5 = h->de_v2 && !h->de_v4 && de5_fits(d) && h->lds_de5 <= 150 * 1024 && getenv("TTX_DE_V5") && atoi(getenv("TTX_DE_V5")) == 1;
     }
     if (cfg->fun_id == TTX_FUN_MVN) {
         std::vector<double> t((size_t)d * d);
@@ -585,6 +590,8 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
             h->lds_dew = sizeof(double) * de_wave_lds_doubles(d);
             h->lot_wave = h->de_v2 && h->lds_dew <= 150 * 1024 && !(getenv("TTX_LOTTERY_WAVE") && atoi(getenv("TTX_LOTTERY_WAVE")) == 0);
             P.bnd_wave = h->lot_wave;
+            h->lds_der = sizeof(double) * de_rows_lds_doubles(d);
+            h->lot_rows = (h->lot_wave && h->lds_der <= 150 * 1024) ? (getenv("TTX_LOTTERY_ROWS") ? atoi(getenv("TTX_LOTTERY_ROWS")) : 1) : 0;
         }
     }
     if (cfg->fun_id == TTX_FUN_HOST) {
@@ -1032,6 +1039,15 @@ static int run_impl(ttx_engine *h)
         static size_t a_d40 = 0, a_d41 = 0;
         if (h->de_v4 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de4<true>), h->lds_de4, a_d40)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de4<false>), h->lds_de4, a_d41)))) return rc;
+        static size_t a_d50 = 0, a_d51 = 0;
+        if (h->de_v5 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de5<true>), h->lds_de5, a_d50)) ||
+                         (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de5<false>), h->lds_de5, a_d51)))) return rc;
+        static size_t a_lr0 = 0, a_lr1 = 0;
+        static size_t a_lr2 = 0, a_lr3 = 0;
+        if (h->lot_rows && ((rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de_rows<true, false>), h->lds_der, a_lr0)) ||
+                            (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de_rows<false, false>), h->lds_der, a_lr1)) ||
+                            (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de_rows<true, true>), h->lds_der, a_lr2)) ||
+                            (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de_rows<false, true>), h->lds_der, a_lr3)))) return rc;
         static size_t a_lw0 = 0, a_lw1 = 0;
         if (h->lot_wave && ((rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de<true>), h->lds_dew, a_lw0)) ||
                             (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de<false>), h->lds_dew, a_lw1)))) return rc;
@@ -1135,7 +1151,14 @@ static int run_impl(ttx_engine *h)
                 } else if (FUN == FUN_ISING && h->lot_wave) {
                     KScope ks(h, TTX_K_LOTTERY, 3);
                     hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 1);
-                    if (P.de_unit) hipLaunchKernelGGL(k_lottery_eval_de<true>, dim3(P.lot_max, G), dim3(64), h->lds_dew, st, P);
+                    if (h->lot_rows) {
+                        const dim3 gr((P.lot_max + 3) / 4, G);
+                        if (h->lot_rows == 2) {         // TTX_LOTTERY_ROWS=2: with the pivots' factor tables (measured slower: HBM latency)
+                            if (P.de_unit) hipLaunchKernelGGL((k_lottery_eval_de_rows<true, true>), gr, dim3(64), h->lds_der, st, P);
+                            else hipLaunchKernelGGL((k_lottery_eval_de_rows<false, true>), gr, dim3(64), h->lds_der, st, P);
+                        } else if (P.de_unit) hipLaunchKernelGGL((k_lottery_eval_de_rows<true, false>), gr, dim3(64), h->lds_der, st, P);
+                        else hipLaunchKernelGGL((k_lottery_eval_de_rows<false, false>), gr, dim3(64), h->lds_der, st, P);
+                    } else if (P.de_unit) hipLaunchKernelGGL(k_lottery_eval_de<true>, dim3(P.lot_max, G), dim3(64), h->lds_dew, st, P);
                     else hipLaunchKernelGGL(k_lottery_eval_de<false>, dim3(P.lot_max, G), dim3(64), h->lds_dew, st, P);
                     hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 2);
                 } else
@@ -1145,7 +1168,10 @@ static int run_impl(ttx_engine *h)
                     for (int hh = 0; hh < h->H; hh++) hipLaunchKernelGGL(k_halfstep_mvn, dim3(h->de_slots, G), dim3(64), h->lds_mvn, st, P, hh, dir, h->mode);
                 } else if (FUN == FUN_ISING && h->de_v2) {
                     for (int hh = 0; hh < h->H; hh++) {
-                        if (h->de_v4) {
+                        if (h->de_v5) {
+                            if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de5<true>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
+                            else hipLaunchKernelGGL(k_halfstep_de5<false>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
+                        } else if (h->de_v4) {
                             if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de4<true>, dim3(h->de_slots, G), dim3(256), h->lds_de4, st, P, hh, dir, h->mode);
                             else hipLaunchKernelGGL(k_halfstep_de4<false>, dim3(h->de_slots, G), dim3(256), h->lds_de4, st, P, hh, dir, h->mode);
                         } else if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de<true>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
@@ -1345,6 +1371,18 @@ extern "C" int ttx_run(ttx_engine *h)
                 h->cluster = 0; h->cluster_aborted = false; h->cluster_fallbacks++;
                 for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
                 rc = run_impl<FUN_ISING>(h);
+            }
+            if (!rc && h->de_v5) {
+                // the relay of k_halfstep_de5 reports a broken hand-over (bounded waits) in ctl[3]: nothing of such a run is
+                // kept, the relay is retired for this engine and the run repeated with k_halfstep_de (identical results)
+                int faults = 0;
+                HIPCHECK(hipMemcpy(&faults, h->P.ctl + 3, sizeof(int), hipMemcpyDeviceToHost));
+                if (faults) {
+                    if (h->W > 1) return fail(TTX_EHIP, "ttx_run: the wave relay of k_halfstep_de5 broke (%d hand-overs); set TTX_DE_V5=0", faults);
+                    h->de_v5 = 0; h->de5_fallbacks++;
+                    for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
+                    rc = run_impl<FUN_ISING>(h);
+                }
             }
             return rc;
         }

@@ -265,6 +265,49 @@ __device__ __forceinline__ double de_t2(double u)
     const double t = FAST ? fdiv_unit(n, d) : n / d;
     return t * t;
 }
+// W independent pair factors at once, written STAGE BY STAGE.  One division is a chain of nine dependent fp64
+// instructions, most of them FMAs with two or three VGPR operands, which a lone wave issues only every ~8.5 cycles
+// (profiles/r02_probe_dpp.txt: 3.5 ns per instruction against 1.9 ns with constant operands).  Measured per pair on one
+// wave: 85 ns with one chain, 57 with two, 42 with four (what the compiler makes of four de_t2 calls), 35 with eight
+// chains interleaved -- the SIMD's own limit with several resident waves is 29 ns.  Same operations per element as
+// de_t2 / fdiv_unit, so the same bits.
+template <bool FAST, int W>
+__device__ __forceinline__ void de_t2xw(const double (&u)[W], double (&t)[W])
+{
+    if (!FAST) {
+#pragma unroll
+        for (int k = 0; k < W; k++) t[k] = de_t2<false>(u[k]);
+        return;
+    }
+    double n[W], d[W], r[W], e[W], q[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) { n[k] = u[k] - 1.0; d[k] = u[k] + 1.0; }
+#pragma unroll
+    for (int k = 0; k < W; k++) r[k] = __builtin_amdgcn_rcp(d[k]);
+#pragma unroll
+    for (int k = 0; k < W; k++) e[k] = __builtin_fma(-d[k], r[k], 1.0);
+#pragma unroll
+    for (int k = 0; k < W; k++) r[k] = __builtin_fma(r[k], e[k], r[k]);
+#pragma unroll
+    for (int k = 0; k < W; k++) e[k] = __builtin_fma(-d[k], r[k], 1.0);
+#pragma unroll
+    for (int k = 0; k < W; k++) r[k] = __builtin_fma(r[k], e[k], r[k]);
+#pragma unroll
+    for (int k = 0; k < W; k++) q[k] = n[k] * r[k];
+#pragma unroll
+    for (int k = 0; k < W; k++) e[k] = __builtin_fma(-d[k], q[k], n[k]);
+#pragma unroll
+    for (int k = 0; k < W; k++) q[k] = __builtin_fma(e[k], r[k], q[k]);
+#pragma unroll
+    for (int k = 0; k < W; k++) t[k] = q[k] * q[k];
+}
+template <bool FAST>
+__device__ __forceinline__ void de_t2x4(double u1, double u2, double u3, double u4, double &t1, double &t2, double &t3, double &t4)
+{
+    const double u[4] = {u1, u2, u3, u4}; double t[4];
+    de_t2xw<FAST, 4>(u, t);
+    t1 = t[0]; t2 = t[1]; t3 = t[2]; t4 = t[3];
+}
 
 // Pair product of an element (left pivot row il | s1 | s2 | right pivot row q) from the per-bond tables built by
 // k_de_tables: the factor ((u_ij-1)/(u_ij+1))^2 of a pair depends only on the dims i+1..j, so every pair that lies
