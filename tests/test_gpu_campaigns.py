@@ -26,13 +26,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _random_case(rng):
     kind = rng.choice(["c", "c", "c", "d", "e", "stdnorm", "mvn"])
+    long_de = kind in ("d", "e") and rng.random() < 0.4     # long pair chains: several 16-column chunks per row, 8-wide division batches
     if kind in ("c", "d", "e"):
-        m = int(rng.integers(3, 40 if kind == "c" else 14))
+        m = int(rng.integers(3, 40 if kind == "c" else 90 if long_de else 14))
         d = m - 1
     else:
         m = d = int(rng.integers(2, 14))
-    n = int(rng.choice([2, 3, 5, 9, 17, 25, 33, 41]))
-    r = int(rng.integers(2, 40 if kind == "c" else 14))
+    n = int(rng.choice([2, 3, 5, 9, 17] if long_de else [2, 3, 5, 9, 17, 25, 33, 41]))
+    r = int(rng.integers(2, 40 if kind == "c" else 9 if long_de else 14))
     piv = int(rng.choice([-1, 0, 1, 2, 3, 4])) if r * n <= 160 else int(rng.choice([0, 1, 2, 3]))
     ng = int(rng.integers(1, min(5, d - 1) + 1)) if d > 2 else 1
     return kind, m, n, r, piv, ng

@@ -22,7 +22,9 @@ def _run_both(s, r, piv, nproc=1):
 
 ISING_CASES = [("c", 6, 33, 20, 2), ("c", 6, 33, 10, 1), ("c", 5, 17, 8, 0), ("c", 8, 25, 12, 3), ("d", 6, 33, 12, 2),
                ("e", 5, 33, 12, 2), ("d", 12, 33, 10, 2), ("c", 16, 51, 32, 2), ("c", 64, 51, 32, 2),
-               ("c", 5, 9, 6, -1), ("d", 4, 11, 5, -1), ("d", 32, 33, 12, 2)]
+               ("c", 5, 9, 6, -1), ("d", 4, 11, 5, -1), ("d", 32, 33, 12, 2),
+               # long chains: several 16-column chunks per row of the pair triangle in the row-wise lottery kernel, 8-wide division batches
+               ("d", 50, 9, 6, 2), ("e", 70, 5, 4, 1), ("d", 100, 17, 10, 3)]
 
 
 @pytest.mark.parametrize("kind,m,n,r,piv", ISING_CASES, ids=[f"{c[0]}{c[1]}_n{c[2]}_r{c[3]}_p{c[4]}" for c in ISING_CASES])
@@ -46,7 +48,7 @@ def test_ising_sweep_bit_exact(kind, m, n, r, piv):
 
 
 GROUP_CASES = [("c", 6, 33, 20, 2, 2), ("c", 6, 33, 20, 2, 4), ("d", 8, 33, 10, 2, 3), ("c", 16, 51, 32, 2, 8), ("c", 64, 51, 32, 2, 8),
-               ("c", 64, 51, 32, 2, 5), ("e", 9, 33, 12, 3, 7), ("c", 7, 9, 5, -1, 2), ("c", 12, 17, 6, 0, 3)]
+               ("c", 64, 51, 32, 2, 5), ("e", 9, 33, 12, 3, 7), ("c", 7, 9, 5, -1, 2), ("c", 12, 17, 6, 0, 3), ("d", 60, 9, 6, 2, 4)]
 
 
 @pytest.mark.parametrize("kind,m,n,r,piv,nproc", GROUP_CASES, ids=[f"{c[0]}{c[1]}_r{c[3]}_p{c[4]}_np{c[5]}" for c in GROUP_CASES])
@@ -513,6 +515,23 @@ def test_both_sweep_paths_bit_exact(monkeypatch, fused, kind, m, n, r, piv, npro
     assert [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]]
     assert [a["neval"] for a in tt.sweeps()] == [b["neval"] for b in oo["sweeps"]]
     assert tt.quad(s["quad"]) == oo["value"]
+
+
+@pytest.mark.parametrize("env", [{"TTX_DE_FASTDIV": "0"}, {"TTX_LOTTERY_ROWS": "2"}, {"TTX_LOTTERY_WAVE": "0"}, {"TTX_DE_V5": "1"}, {"TTX_DE_V2": "0"}],
+                         ids=["general_division", "lottery_rows_with_tables", "lottery_lane_per_candidate", "relay_halfstep", "lane_per_element"])
+def test_ising_de_kernel_variants_bit_exact(env, monkeypatch):
+    """Every selectable variant of the D/E kernels gives the oracle's bits: the IEEE division instead of the short sequence for
+    nodes in [0,1], the row-wise lottery with the pivots' factor tables (default: without), the lottery and the boundary corners
+    with one lane per element, the four-wave relay half-step, the round-1 lane-per-element kernels.  The second case has two
+    bond groups (boundary corners)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for kind, m, n, r, piv, ng in [("d", 45, 9, 6, 2, 1), ("e", 38, 5, 5, 3, 2)]:
+        s = D.ising_setup(kind, m, n)
+        tt, oo = _run_both(s, r, piv, nproc=ng)
+        assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d])
+        assert [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]]
+        assert tt.neval == oo["neval"] and tt.quad(s["quad"]) == oo["value"]
 
 
 def test_full_size_d256_against_reference_value():

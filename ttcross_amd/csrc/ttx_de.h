@@ -246,18 +246,6 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// One element per WAVE (lottery candidates, boundary corners): the chip holds few of these evaluations at a time, and a
-// lone lane needs ~32 640 x 20 cycles for one.  Here the 64 lanes share ONE element, so every operand is wave-uniform:
-//   * division phase: lane r of a tile owns ROW i0+r of the pair triangle (rows are independent: each has its own
-//     running product u) and writes its factors ((u-1)/(u+1))^2 to an LDS tile T2[r][.] -- RT rows per tile;
-//   * product phase: all lanes multiply the tile's factors into `a` in the reference's order (row by row, LDS
-//     broadcasts), with the tabulated factors of the pivots streamed in between (WStream) when tables exist.
-// The value of `a` -- and everything after it -- is computed redundantly and identically by all lanes.
-// ------------------------------------------------------------------------------------------------------------------
-#define DE_RT 16                 // rows of pair factors per LDS tile
-__host__ __device__ inline size_t de_wave_lds_doubles(int m) { const int VS = ((m + 7) & ~7) + 8; return (size_t)3 * VS + 128 + (size_t)DE_RT * (VS + 1); }
-
 // b-part (id 2) and weights (test_crs_ising.f90:197-218) from per-dimension value arrays xv / wv (0-based dims)
 __device__ __forceinline__ double de_finish_vals(int id, double a, int m, const double *xv, const double *wv)
 {
@@ -273,268 +261,6 @@ __device__ __forceinline__ double de_finish_vals(int id, double a, int m, const 
     return f;
 }
 
-__device__ __forceinline__ double de_row_chain(double a, const double *row, int len) { return lds_chain(a, row, len); }
-
-// pair product of ONE element without tables: every pair (i, j), 0 <= i < j <= m, by division.  xv[0..m) in LDS.
-template <bool FAST>
-__device__ __forceinline__ double de_elem_full(int m, const double *xv, double *T2, int lane)
-{
-    const int RS = ((m + 7) & ~7) + 9;                 // odd row stride in doubles: 16 rows hit 16 different bank pairs
-    double a = 1.0;
-    for (int i0 = 0; i0 < m; i0 += DE_RT) {
-        const int nr = min(DE_RT, m - i0), maxlen = m - i0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < nr) {
-            const int i = i0 + lane, len = m - i;      // row i: pairs (i, i+1..m), factors of dims i+1..m = xv[i..m)
-            double u = 1.0;
-            double *row = T2 + (size_t)lane * RS;
-            for (int c = 0; c < maxlen; c++) {
-                if (c < len) { u = u * xv[i + c]; row[c] = de_t2<FAST>(u); }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int r = 0; r < nr; r++) a = de_row_chain(a, T2 + (size_t)r * RS, m - (i0 + r));
-    }
-    return a;
-}
-
-// the same with the pivots' tables: rows 0..A+1 carry only the bond-spanning pairs (B+2 per row; row A+1 starts after
-// dim p, its first slot holds the neutral 1.0), TL factors are streamed before each row, TR factors after the last
-template <bool FAST>
-__device__ __forceinline__ double de_elem_tab(int m, int A, const double *xv, const double *UL, WStream &sl, WStream &sr, double *T2, int lane)
-{
-    const int RS = ((m + 7) & ~7) + 9;
-    const int B = m - A - 2, nrow = A + 2, len = B + 2;
-    const double x1 = xv[A], x2 = xv[A + 1];
-    const double *xr = xv + A + 2;
-    double a = 1.0;
-    for (int i0 = 0; i0 < nrow; i0 += DE_RT) {
-        const int nr = min(DE_RT, nrow - i0);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < nr) {
-            const int i = i0 + lane;
-            double *row = T2 + (size_t)lane * RS;
-            double u = 1.0;
-            if (i <= A) { u = UL[i] * x1; row[0] = de_t2<FAST>(u); } else row[0] = 1.0;
-            u = u * x2; row[1] = de_t2<FAST>(u);
-            int j = 0;
-            for (; j + 4 <= B; j += 4) {
-                const double u1 = u * xr[j], u2 = u1 * xr[j + 1], u3 = u2 * xr[j + 2], u4 = u3 * xr[j + 3];
-                de_t2x4<FAST>(u1, u2, u3, u4, row[2 + j], row[3 + j], row[4 + j], row[5 + j]);
-                u = u4;
-            }
-            for (; j < B; j++) { u = u * xr[j]; row[2 + j] = de_t2<FAST>(u); }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int r = 0; r < nr; r++) {
-            const int i = i0 + r;
-            if (i <= A) a = sl.chain(a, A - i, lane);
-            a = de_row_chain(a, T2 + (size_t)r * RS, len);
-        }
-    }
-    return sr.chain(a, B * (B + 1) / 2, lane);
-}
-
-// lottery candidates (lib/dmrgg.f90:455-463) of the Ising D / E integrands: one candidate per wave.  grid = (nlot, groups).
-// The candidates were drawn by k_lottery (phase 1) into P.lotc; values go to P.lotf for k_lottery (phase 2).
-template <bool FAST>
-__global__ __launch_bounds__(64) void k_lottery_eval_de(DevProb P)
-{
-    extern __shared__ __align__(16) double dyn[];
-    const int g = blockIdx.y, il = blockIdx.x, lane = threadIdx.x, m = P.d;
-    const GroupState &gs = P.gs[g];
-    const StepState &st = gs.S[0];
-    if (!st.active) return;
-    const int p = st.p, first = gs.first;
-    const int nlot = st.r0 + st.n1 + st.n2 + st.r2;
-    if (il >= nlot) return;
-    const int *cand = P.lotc + ((size_t)g * P.lot_max + il) * 4;
-    const int ci = cand[0] - 1, cj = cand[1] - 1, ck = cand[2] - 1, cq = cand[3] - 1;
-    const int A = p - 1, B = m - p - 1, VS = ((m + 7) & ~7) + 8, n1m = P.n[1];
-    double *xv = dyn, *wv = xv + VS, *UL = wv + VS, *ringL = UL + VS, *ringR = ringL + 64, *T2 = ringR + 64;
-    const double *nodes = P.par, *weights = P.par + n1m;
-    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
-    for (int x = lane; x < m; x += 64) {
-        const int ix = (x < A) ? Lt[(size_t)x * P.RM + ci] - 1 : (x == A) ? cj : (x == A + 1) ? ck : Rt[(size_t)(x - A - 2) * P.RM + cq] - 1;
-        xv[x] = nodes[ix]; wv[x] = weights[ix];
-    }
-    const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
-    const double *ULg = P.deUL + ((size_t)g * P.RM + ci) * (m + 1);
-    for (int x = lane; x <= A; x += 64) UL[x] = ULg[x];
-    WStream sl, sr;
-    sl.init(P.deTL + (size_t)g * tsz + (size_t)ci * NP, A * (A + 1) / 2, ringL, lane);
-    sr.init(P.deTR + (size_t)g * tsz + (size_t)cq * NP, B * (B + 1) / 2, ringR, lane);
-    __syncthreads();
-    const double a = de_elem_tab<FAST>(m, A, xv, UL, sl, sr, T2, lane);
-    const double f = de_finish_vals(P.ising_id, a, m, xv, wv);
-    if (lane == 0) P.lotf[(size_t)g * P.lot_max + il] = f;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// k_halfstep_de4: the same half-step with the work of ONE (pivot, mode-chunk) spread over the four SIMDs of a CU.
-// Measured unit costs (profiles/r02_fold_probe.txt): a bond-spanning pair with its exact division costs 39 ns of one wave's
-// issue slots, an ordered multiply of a ready factor 2.6-5.8 ns -- and a launch holds ~1.25 waves per CU, three SIMDs idle.
-// So a workgroup of FOUR waves shares the 64 elements (lane = mode index in every wave):
-//   waves 1..3, the DIVIDERS: each runs the cheap running product u of the row (one multiply per pair) and performs the
-//     divisions of every third pair -- twelve pairs per step, four independent divisions per divider -- writing
-//     ((u-1)/(u+1))^2 into an LDS tile T2[pair][lane];
-//   wave 0, the FOLDER: streams the tabulated factors (TL / TR) and multiplies the tiles' factors into the products `a`
-//     in the reference's order; it alone owns `a`, the b-part, the weights, the residual and the arg-max record.
-// One workgroup barrier per tile of 36 pairs; the tiles are double-buffered, so the dividers work on tile k+1 while the
-// folder folds tile k.  Every product is still taken by one lane in the reference's order: bit-identical.
-// ------------------------------------------------------------------------------------------------------------------
-#define DE4_TJ 36                // pairs per tile (three steps of twelve)
-__host__ __device__ inline size_t de4_lds_doubles(int m) { const int VS = ((m + 7) & ~7) + 8; return (size_t)5 * VS + 128 + (size_t)2 * DE4_TJ * 64; }
-
-template <bool FAST>
-__global__ __launch_bounds__(256) void k_halfstep_de4(DevProb P, int h, int dir, int mode)
-{
-    extern __shared__ __align__(16) double dyn[];
-    __shared__ StepState cur;
-    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = P.d;
-    GroupState &gs = P.gs[g];
-    if (tid == 0) { cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]); }
-    __syncthreads();
-    if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
-    const bool iscol = (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
-    const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
-    const int nf = iscol ? r0 * n1 : n2 * r2;
-    const int nv = iscol ? r0 : r2, nm = iscol ? n1 : n2, nch = (nm + 63) >> 6;
-    const int npart = nv * nch;
-    const int w = blockIdx.x;
-    const int crs = cur.crs + 1;
-    const int havecol = cur.havecol | (iscol ? 1 : 0), haverow = cur.haverow | (iscol ? 0 : 1);
-    const int done = (mode == 1 || mode == 2) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
-    const bool resid = (mode == 0) && !done;
-    if (w == 0 && tid == 0) {
-        StepState nx = cur;
-        nx.crs = crs; nx.havecol = havecol; nx.haverow = haverow; nx.done = done;
-        nx.pending = resid ? (iscol ? 1 : 2) : 0;
-        nx.npart = npart;
-        gs.S[h + 1] = nx;
-        if (mode != 2) gs.neval += nf;                                        // :527 / :560 / :509
-        gs.bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
-        gs.n_resid += resid ? 1 : 0;
-    }
-    if (w >= npart) return;
-    const int pv = w / nch, vmode = (w - pv * nch) * 64 + lane;
-    const bool live = vmode < nm;
-    const int A = p - 1, B = m - p - 1;
-    const int pl = iscol ? pv : cur.ii - 1, qr = iscol ? cur.qq - 1 : pv;
-    const int n1m = P.n[1];
-    const double *nodes = P.par, *weights = P.par + n1m;
-    const int VS = ((m + 7) & ~7) + 8;
-    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *xr = wl + VS, *wr = xr + VS, *ringL = wr + VS, *ringR = ringL + 64, *T2 = ringR + 64;
-    const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
-    const double *TLg = P.deTL + (size_t)g * tsz + (size_t)pl * NP, *TRg = P.deTR + (size_t)g * tsz + (size_t)qr * NP;
-    const double *ULg = P.deUL + ((size_t)g * P.RM + pl) * (m + 1);
-    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
-    for (int x = tid; x < A; x += 256) { const int ix = Lt[(size_t)x * P.RM + pl] - 1; xl[x] = nodes[ix]; wl[x] = weights[ix]; }
-    for (int x = tid; x < B; x += 256) { const int ix = Rt[(size_t)x * P.RM + qr] - 1; xr[x] = nodes[ix]; wr[x] = weights[ix]; }
-    for (int x = tid; x <= A; x += 256) UL[x] = ULg[x];
-    const int i1 = iscol ? (live ? vmode : 0) : cur.jj - 1, i2 = iscol ? cur.kk - 1 : (live ? vmode : 0);
-    const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
-    __syncthreads();
-    // The spanning pairs of row i (0 <= i <= A+1) as ONE sequence of factors applied to u0: [x1 (rows <= A only), x2, xr[0..B)].
-    // Positions are numbered c = 0 .. len-1 with len = B+2 (rows <= A) or B+1 (row A+1); tile t of a row holds c in
-    // [TJ t, TJ t + TJ).  Everybody walks rows and tiles in the same order and meets at ONE barrier per tile.
-    double a = 1.0;
-    WStream sl, sr;
-    if (wv == 0) { sl.init(TLg, A * (A + 1) / 2, ringL, lane); sr.init(TRg, B * (B + 1) / 2, ringR, lane); }
-    int gt = 0;                                              // global tile counter (selects the buffer)
-    int prev_len = 0; const double *prev_buf = nullptr;      // folder: the tile handed over at the last barrier
-    int prev_first_of_row = 0, prev_row = 0;
-    for (int i = 0; i <= A + 1; i++) {
-        const int len = (i <= A) ? B + 2 : B + 1;
-        double u = (i <= A) ? UL[i] : 1.0;
-        for (int c0 = 0; c0 < len; c0 += DE4_TJ, gt++) {
-            const int tl = min(DE4_TJ, len - c0);
-            double *buf = T2 + (size_t)(gt & 1) * DE4_TJ * 64;
-            if (wv != 0) {
-                // dividers: running product over the tile, every third pair divided here (divider wv-1 takes c = wv-1 mod 3)
-                auto fac = [&](int c) -> double { const int k = (i <= A) ? c : c + 1; return (k == 0) ? x1 : (k == 1) ? x2 : xr[k - 2]; };
-                int c = 0;
-                for (; c + 12 <= tl; c += 12) {
-                    double uu[12];
-#pragma unroll
-                    for (int q = 0; q < 12; q++) { u = u * fac(c0 + c + q); uu[q] = u; }
-                    double mine[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) mine[q] = (wv == 1) ? uu[3 * q] : (wv == 2) ? uu[3 * q + 1] : uu[3 * q + 2];
-                    double t2v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) t2v[q] = de_t2<FAST>(mine[q]);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) buf[(size_t)(c + 3 * q + (wv - 1)) * 64 + lane] = t2v[q];
-                }
-                for (; c < tl; c++) {                         // tail of the row: pair by pair, round robin
-                    u = u * fac(c0 + c);
-                    if ((c % 3) == wv - 1) buf[(size_t)c * 64 + lane] = de_t2<FAST>(u);
-                }
-            } else if (prev_buf) {
-                // folder: the tile of the previous barrier (its row's tabulated factors first, if it opens the row)
-                if (prev_first_of_row && prev_row <= A) a = sl.chain(a, A - prev_row, lane);
-#pragma unroll 4
-                for (int c = 0; c < prev_len; c++) a = a * prev_buf[(size_t)c * 64 + lane];
-            }
-            __syncthreads();
-            prev_buf = buf; prev_len = tl; prev_first_of_row = (c0 == 0); prev_row = i;
-        }
-    }
-    if (wv != 0) return;                                     // dividers are done
-    if (prev_buf) {
-        if (prev_first_of_row && prev_row <= A) a = sl.chain(a, A - prev_row, lane);
-        for (int c = 0; c < prev_len; c++) a = a * prev_buf[(size_t)c * 64 + lane];
-    }
-    a = sr.chain(a, B * (B + 1) / 2, lane);
-    // ---- b-part (id 2) and the weights (:197-218), order of de_finish ----
-    const int id = P.ising_id;
-    double b = 0.0;
-    if (id == 2) {
-        double v = 1.0, ww = 1.0, vk = 1.0, wk = 1.0;
-        for (int j = B - 1; j >= 0; j--) { vk = vk * xr[j]; v = v + vk; }
-        vk = vk * x2; v = v + vk;
-        vk = vk * x1; v = v + vk;
-        for (int j = A - 1; j >= 0; j--) { vk = vk * xl[j]; v = v + vk; }
-        for (int j = 0; j < A; j++) { wk = wk * xl[j]; ww = ww + wk; }
-        wk = wk * x1; ww = ww + wk;
-        wk = wk * x2; ww = ww + wk;
-        for (int j = 0; j < B; j++) { wk = wk * xr[j]; ww = ww + wk; }
-        b = 1.0 / (v * ww);
-    }
-    double f = (id == 2) ? 2 * a * b : 2 * a;
-    for (int j = 0; j < A; j++) f = f * wl[j];
-    f = f * w1; f = f * w2;
-    for (int j = 0; j < B; j++) f = f * wr[j];
-    a = f;
-    const int u_ = iscol ? pv : vmode, v_ = iscol ? vmode : pv;
-    const int t = iscol ? (u_ + r0 * v_) : (u_ + n2 * v_);
-    if (live) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
-    const double mx = wave_max(live ? fabs(a) : 0.0);
-    if (lane == 0 && mode != 1) atomic_max_pos(&gs.amax, mx);
-    if (resid) {
-        const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
-        double bb = a, ab = -1.0; int bi = INT_MAX;
-        if (live) {
-            if (iscol) {
-                const double *c = Cp + u_ + (size_t)P.RM * v_;
-                const double *xq = Wq + (cur.kk - 1) + (size_t)P.NM * (cur.qq - 1);
-#pragma unroll 8
-                for (int s = 0; s < r1; s++) bb = bb + (-xq[P.SW * s]) * c[P.SS * s];
-            } else {
-                const double *wvp = Wq + u_ + (size_t)P.NM * v_;
-                const double *xc = Cp + (cur.ii - 1) + (size_t)P.RM * (cur.jj - 1);
-                double tt = 0.0;
-#pragma unroll 8
-                for (int s = 0; s < r1; s++) tt = tt + wvp[P.SW * s] * xc[P.SS * s];
-                bb = bb + (-1.0) * tt;
-            }
-            ab = fabs(bb); bi = t;
-        }
-        wave_argmax(ab, bb, bi);
-        if (lane == 0) { Partial pr; pr.absmax = ab; pr.val = bb; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][w] = pr; }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_halfstep_de5: the half-step of ONE (pivot, mode-chunk) by a RELAY of four waves (round 2; measured unit costs in
@@ -749,7 +475,8 @@ __global__ __launch_bounds__(64 * DE5_W, 2) void k_halfstep_de5(DevProb P, int h
 //     instruction streams in one loop body;
 //   * tabulated factors TL / TR: lane n loads factors 2n, 2n+1 of a 32-factor chunk of ITS candidate's table row, four chunks
 //     ahead.
-// The order of all products is that of de_elem_tab, the operations per factor those of de_t2: bit-identical.
+// The order of all products is that of de_pairs_tab (the reference's row-major pair loop), the operations per factor those
+// of de_t2: bit-identical.
 // ------------------------------------------------------------------------------------------------------------------
 template <int K> __device__ __forceinline__ double rowbc(double f)
 {
@@ -806,7 +533,7 @@ struct RStream {
     }
 };
 // LDS per DPP row: xv | wv | UL, each RSW doubles; RSW = 16 mod 32 so that the four rows' 16-lane reads hit disjoint bank halves
-__host__ __device__ inline int de_rows_stride(int m) { int s = m + 56; return ((s + 31) & ~31) + 16; }
+__host__ __device__ inline int de_rows_stride(int m) { const int s = m + 56; return ((s + 31) & ~31) + 16; }
 __host__ __device__ inline size_t de_rows_lds_doubles(int m) { return (size_t)12 * de_rows_stride(m); }
 
 // One row of the pair triangle for the four candidates of a wave: a = a * t(u0 xs[0]) * t(u0 xs[0] xs[1]) * ... (L factors,

@@ -135,12 +135,11 @@ struct ttx_engine {
     size_t lds_half = 0, lds_lot = 0, lds_par = 0;
     int half_vals = 0, lot_vals = 0;
     int de_v2 = 0;                      // Ising D/E: wave-per-pivot half-step kernel k_halfstep_de (ttx_de.h)
-    int de_v4 = 0; size_t lds_de4 = 0;  // ... with three divider waves beside the folder wave (k_halfstep_de4)
     int de_v5 = 0; size_t lds_de5 = 0;  // ... as a relay of four waves (k_halfstep_de5): the default where it fits
     int de5_fallbacks = 0;
     int de_slots = 0; size_t lds_de = 0;
     int lot_rows = 0; size_t lds_der = 0;   // ... four candidates per wave, one per DPP row (k_lottery_eval_de_rows)
-    int lot_wave = 0; size_t lds_dew = 0;   // Ising D/E: lottery candidates and boundary corners one element per wave (ttx_de.h)
+    int lot_wave = 0;                       // Ising D/E: lottery candidates and boundary corners by the row-wise wave evaluator (ttx_de.h)
     int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
@@ -383,12 +382,8 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         h->lds_de = sizeof(double) * (5 * (size_t)(((d + 7) & ~7) + 8) + 128);
         h->de_v2 = cfg->pivoting >= 0 && h->de_slots <= TTX_MAXPART && h->lds_de <= 150 * 1024 &&
                    !(getenv("TTX_DE_V2") && atoi(getenv("TTX_DE_V2")) == 0);
-        h->lds_de4 = sizeof(double) * de4_lds_doubles(d);
-        // measured and NOT adopted (D_256: k_halfstep_de 4.70 s -> k_halfstep_de4 5.79 s per run): the three dividers each re-read the
-        // node values as LDS broadcasts and meet the folder at a barrier every 36 pairs; opt-in for experiments only
-        h->de_v4 = h->de_v2 && h->lds_de4 <= 150 * 1024 && getenv("TTX_DE_V4") && atoi(getenv("TTX_DE_V4")) == 1;
         h->lds_de5 = sizeof(double) * de5_lds_doubles(d);
-        h->de_v5 = h->de_v2 && !h->de_v4 && de5_fits(d) && h->lds_de5 <= 150 * 1024 && getenv("TTX_DE_V5") && atoi(getenv("TTX_DE_V5")) == 1;
+        h->de_v5 = h->de_v2 && de5_fits(d) && h->lds_de5 <= 150 * 1024 && getenv("TTX_DE_V5") && atoi(getenv("TTX_DE_V5")) == 1;
     }
     if (cfg->fun_id == TTX_FUN_MVN) {
         std::vector<double> t((size_t)d * d);
@@ -587,11 +582,11 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
             rc = dev_alloc(h, &lcd, (size_t)h->G * nlotmax * 4); if (rc) { ttx_destroy(h); return rc; }
             rc = dev_alloc(h, &lf, (size_t)h->G * nlotmax); if (rc) { ttx_destroy(h); return rc; }
             P.lotc = lcd; P.lotf = lf;
-            h->lds_dew = sizeof(double) * de_wave_lds_doubles(d);
-            h->lot_wave = h->de_v2 && h->lds_dew <= 150 * 1024 && !(getenv("TTX_LOTTERY_WAVE") && atoi(getenv("TTX_LOTTERY_WAVE")) == 0);
-            P.bnd_wave = h->lot_wave;
+            // candidates and boundary corners by the row-wise wave evaluator (ttx_de.h); TTX_LOTTERY_WAVE=0: one lane per element
             h->lds_der = sizeof(double) * de_rows_lds_doubles(d);
-            h->lot_rows = (h->lot_wave && h->lds_der <= 150 * 1024) ? (getenv("TTX_LOTTERY_ROWS") ? atoi(getenv("TTX_LOTTERY_ROWS")) : 1) : 0;
+            h->lot_wave = h->de_v2 && h->lds_der <= 150 * 1024 && !(getenv("TTX_LOTTERY_WAVE") && atoi(getenv("TTX_LOTTERY_WAVE")) == 0);
+            P.bnd_wave = h->lot_wave;
+            h->lot_rows = h->lot_wave ? ((getenv("TTX_LOTTERY_ROWS") && atoi(getenv("TTX_LOTTERY_ROWS")) == 2) ? 2 : 1) : 0;
         }
     }
     if (cfg->fun_id == TTX_FUN_HOST) {
@@ -1036,9 +1031,6 @@ static int run_impl(ttx_engine *h)
         static size_t a_de0 = 0, a_de1 = 0;
         if (h->de_v2 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<true>), h->lds_de, a_de0)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<false>), h->lds_de, a_de1)))) return rc;
-        static size_t a_d40 = 0, a_d41 = 0;
-        if (h->de_v4 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de4<true>), h->lds_de4, a_d40)) ||
-                         (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de4<false>), h->lds_de4, a_d41)))) return rc;
         static size_t a_d50 = 0, a_d51 = 0;
         if (h->de_v5 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de5<true>), h->lds_de5, a_d50)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de5<false>), h->lds_de5, a_d51)))) return rc;
@@ -1048,9 +1040,6 @@ static int run_impl(ttx_engine *h)
                             (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de_rows<false, false>), h->lds_der, a_lr1)) ||
                             (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de_rows<true, true>), h->lds_der, a_lr2)) ||
                             (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de_rows<false, true>), h->lds_der, a_lr3)))) return rc;
-        static size_t a_lw0 = 0, a_lw1 = 0;
-        if (h->lot_wave && ((rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de<true>), h->lds_dew, a_lw0)) ||
-                            (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_de<false>), h->lds_dew, a_lw1)))) return rc;
     }
     if (h->cluster) *h->h_abort = 0;
     // an evaluating kernel: once with the device integrand; with a host integrand twice around the host's calls
@@ -1151,15 +1140,14 @@ static int run_impl(ttx_engine *h)
                 } else if (FUN == FUN_ISING && h->lot_wave) {
                     KScope ks(h, TTX_K_LOTTERY, 3);
                     hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 1);
-                    if (h->lot_rows) {
+                    {
                         const dim3 gr((P.lot_max + 3) / 4, G);
                         if (h->lot_rows == 2) {         // TTX_LOTTERY_ROWS=2: with the pivots' factor tables (measured slower: HBM latency)
                             if (P.de_unit) hipLaunchKernelGGL((k_lottery_eval_de_rows<true, true>), gr, dim3(64), h->lds_der, st, P);
                             else hipLaunchKernelGGL((k_lottery_eval_de_rows<false, true>), gr, dim3(64), h->lds_der, st, P);
                         } else if (P.de_unit) hipLaunchKernelGGL((k_lottery_eval_de_rows<true, false>), gr, dim3(64), h->lds_der, st, P);
                         else hipLaunchKernelGGL((k_lottery_eval_de_rows<false, false>), gr, dim3(64), h->lds_der, st, P);
-                    } else if (P.de_unit) hipLaunchKernelGGL(k_lottery_eval_de<true>, dim3(P.lot_max, G), dim3(64), h->lds_dew, st, P);
-                    else hipLaunchKernelGGL(k_lottery_eval_de<false>, dim3(P.lot_max, G), dim3(64), h->lds_dew, st, P);
+                    }
                     hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 2);
                 } else
                 { KScope ks(h, TTX_K_LOTTERY); if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_lottery<FUN>, dim3(P.lot_nb, G), dim3(P.lot_nb == 1 ? 512 : 256), h->lds_lot, st, Q, dir, pp, h->lot_vals, 0); })) return rc_; }
@@ -1171,9 +1159,6 @@ static int run_impl(ttx_engine *h)
                         if (h->de_v5) {
                             if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de5<true>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
                             else hipLaunchKernelGGL(k_halfstep_de5<false>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
-                        } else if (h->de_v4) {
-                            if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de4<true>, dim3(h->de_slots, G), dim3(256), h->lds_de4, st, P, hh, dir, h->mode);
-                            else hipLaunchKernelGGL(k_halfstep_de4<false>, dim3(h->de_slots, G), dim3(256), h->lds_de4, st, P, hh, dir, h->mode);
                         } else if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de<true>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
                         else hipLaunchKernelGGL(k_halfstep_de<false>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
                     }
@@ -1215,7 +1200,7 @@ static int run_impl(ttx_engine *h)
             if (nproc > 1) {
                 const size_t VSb = ((d + 7) & ~7) + 8;
                 const size_t lds_b = h->lds_par + 16 + sizeof(short) * 2 * VSb + sizeof(double) * (64 * 64 + 4) +
-                                     (P.bnd_wave ? sizeof(double) * (2 * VSb + (size_t)DE_RT * (VSb + 1) + 8) : 0);    // >= the 3 d doubles of the mvn corner
+                                     (P.bnd_wave ? sizeof(double) * (2 * (size_t)de_rows_stride(d) + 8) : 0);    // >= the 3 d doubles of the mvn corner
                 static size_t a_bnd = 0;
                 if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_exch_boundary<FUN>), lds_b, a_bnd)) return rc_;
                 if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), lds_b, st, Q); })) return rc_;

@@ -1805,20 +1805,26 @@ __global__ __launch_bounds__(256) void k_exch_max_apply(DevProb P, int from_recv
 }
 
 // one element per wave (ttx_de.h)
-template <bool FAST> __device__ __forceinline__ double de_elem_full(int m, const double *xv, double *T2, int lane);
+template <bool FAST> __device__ __forceinline__ double rows_span(double a, double u0, const double *xs, int L, bool neutral0, int n);
+__host__ __device__ inline int de_rows_stride(int m);
 __device__ __forceinline__ double de_finish_vals(int id, double a, int m, const double *xv, const double *wv);
-// corner entry of the Ising D / E integrands by the first wave of the block: multi-index = rowA (dims 1..p-1) | self | rowB
+// corner entry of the Ising D / E integrands by the first wave of the block: multi-index = rowA (dims 1..p-1) | self | rowB.
+// Every pair by division with the row-wise evaluator of the lottery (ttx_de.h): the four DPP rows of the wave work on the same
+// element (lane n of a row = column n of a 16-column chunk of the pair triangle), the result is identical in all lanes.
 __device__ __forceinline__ double de_corner_wave(const DevProb &P, const double *par, const short *rowA, int p, int self, const short *rowB,
                                                  double *scratch, int lane)
 {
-    const int m = P.d, VS = ((m + 7) & ~7) + 8, n1m = P.n[1];
-    double *xv = scratch, *wv = xv + VS, *T2 = wv + VS;
+    const int m = P.d, RSW = de_rows_stride(m), n1m = P.n[1], n = lane & 15;
+    double *xv = scratch, *wv = xv + RSW;
     for (int x = lane; x < m; x += 64) {
         const int ix = ((x < p - 1) ? (int)rowA[x] : (x == p - 1) ? self : (int)rowB[x - p]) - 1;
         xv[x] = par[ix]; wv[x] = par[n1m + ix];
     }
+    if (lane < 56) xv[m + lane] = 1.0;                      // the evaluator's running products read up to 47 columns past a row's end
     __builtin_amdgcn_wave_barrier();
-    const double a = P.de_unit ? de_elem_full<true>(m, xv, T2, lane) : de_elem_full<false>(m, xv, T2, lane);
+    double a = 1.0;
+    if (P.de_unit) for (int i = 0; i < m; i++) a = rows_span<true>(a, 1.0, xv + i, m - i, false, n);
+    else for (int i = 0; i < m; i++) a = rows_span<false>(a, 1.0, xv + i, m - i, false, n);
     return de_finish_vals(P.ising_id, a, m, xv, wv);
 }
 
