@@ -264,29 +264,33 @@ __device__ __forceinline__ double de_finish_vals(int id, double a, int m, const 
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_halfstep_de5: the half-step of ONE (pivot, mode-chunk) by a RELAY of four waves (round 2; measured unit costs in
-// profiles/r02_probe_dpp.txt).  A bond-spanning pair costs 42 ns of a lone wave but only ~30-36 ns of a SIMD's issue slots,
+// profiles/r02_probe_dpp.txt).  A bond-spanning pair costs 35-42 ns of a lone wave but only ~29 ns of a SIMD's issue slots,
 // and a launch of k_halfstep_de has at most r x ceil(n/64) x groups waves -- 624 at D_256, fewer than the chip's 1024 SIMDs.
-// So the body of every row of the pair triangle (the B right dims) is cut into four contiguous segments, one per wave
-// (lane = mode index in every wave).  A wave
-//   * runs the cheap running product u of the row up to its segment (one multiply per pair, LDS broadcasts),
-//   * performs the divisions of its own segment, four at a time, keeping the factors ((u-1)/(u+1))^2 in REGISTERS,
+// So the body of every row of the pair triangle (the B right dims) is dealt out in segments of 16 columns, round robin
+// over four waves (lane = mode index in every wave).  Per round a wave
+//   * moves its running product u over the other waves' 48 columns (one multiply per column, LDS broadcasts),
+//   * performs the 16 divisions of its segment, eight at a time stage by stage, keeping the factors in 32 REGISTERS,
 //   * then waits for the token -- the running product `a` of the element, 64 lanes x 8 bytes in an LDS mailbox --,
-//     multiplies its factors in, in order, and hands the token to the next wave (the last one to wave 0: next row).
+//     multiplies its factors in, in order, and hands the token to the next wave.
 // Wave 0 additionally owns the head of a row (the tabulated factors TL, the pairs with dims p and p+1), the tabulated
 // tail TR, the b-part, the weights, the residual and the arg-max record.  While the token travels, every wave is already
-// dividing for the next row, so a row lasts as long as one wave needs for a QUARTER of its divisions; nothing but the
-// token crosses waves (no tile traffic, no workgroup barrier).  Every product is still taken by one lane in the
-// reference's order: bit-identical to k_halfstep_de and the oracle.
+// dividing for its next segment; nothing but the token crosses waves (no tile traffic, no workgroup barrier).  Every product
+// is still taken by one lane in the reference's order: bit-identical to k_halfstep_de and the oracle.
 // Mailboxes: a slot is either the sentinel (a NaN pattern no arithmetic produces) or a value; the receiver polls its
 // own slot, takes the value and restores the sentinel before it sends on -- LDS operations of one wave complete in order
 // and the next value for this slot can only be produced after the token has passed through the receiver again.
-// Every wait is bounded (a fault would show as a wrong result in the tests, not as a hung GPU).
+// Every wait is bounded; a broken hand-over is reported to the host (ctl[3]), which repeats the run with k_halfstep_de.
+// MEASURED AND NOT ADOPTED (TTX_DE_V5=1 selects it; bit-exact, in the tests): half-steps of D_256 5.05 s against 4.17 s of
+// k_halfstep_de.  Every wave still walks every column of a row with its running product (an LDS-fed multiply, 5.8 ns), so
+// four waves spend 4 x 5.8 ns per pair on top of the 29 ns of the division, and 214 registers allow two waves per SIMD; a
+// token hop costs 140-165 ns.  Two waves with 32-column segments: 5.42 s; 64-column segments in registers (305 registers,
+// one wave per SIMD): 8.5 s.
 // ------------------------------------------------------------------------------------------------------------------
 #define DE5_W 4
-#define DE5_SEG 64               // most body factors per wave and row (B <= 256)
+#define DE5_SEG 16               // columns of a row's body per wave and round
 #define DE5_SENT 0xfff85a5a00000001ull
-__host__ __device__ inline size_t de5_lds_doubles(int m) { const int VS = ((m + 7) & ~7) + 24; return (size_t)5 * VS + 128 + (size_t)DE5_W * 64; }
-__host__ __device__ inline bool de5_fits(int m) { return m - 2 <= DE5_W * DE5_SEG; }
+__host__ __device__ inline size_t de5_lds_doubles(int m) { const int VS = ((m + 7) & ~7) + 8 + DE5_SEG; return (size_t)5 * VS + 128 + (size_t)DE5_W * 64; }
+__host__ __device__ inline bool de5_fits(int m) { return m >= 3; }
 
 __device__ __forceinline__ void de5_send(unsigned long long *box, int lane, double a)
 {
@@ -314,7 +318,7 @@ __device__ __forceinline__ bool de5_recv(unsigned long long *box, int lane, doub
 #define DE5_FAIL() do { if (lane == 0) { atomicAdd(&P.ctl[3], 1); P.ctl[0] = 1; } return; } while (0)
 
 template <bool FAST>
-__global__ __launch_bounds__(64 * DE5_W, 2) void k_halfstep_de5(DevProb P, int h, int dir, int mode)
+__global__ __launch_bounds__(64 * DE5_W) void k_halfstep_de5(DevProb P, int h, int dir, int mode)
 {
     extern __shared__ __align__(16) double dyn[];
     __shared__ StepState cur;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(64 * DE5_W, 2) void k_halfstep_de5(DevProb P, int h
     const int pl = iscol ? pv : cur.ii - 1, qr = iscol ? cur.qq - 1 : pv;
     const int n1m = P.n[1];
     const double *nodes = P.par, *weights = P.par + n1m;
-    const int VS = ((m + 7) & ~7) + 24;
+    const int VS = ((m + 7) & ~7) + 8 + DE5_SEG;
     double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *xr = wl + VS, *wr = xr + VS, *ringL = wr + VS, *ringR = ringL + 64;
     unsigned long long *box = reinterpret_cast<unsigned long long *>(ringR + 64);          // [DE5_W][64]
     const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
@@ -360,17 +364,16 @@ __global__ __launch_bounds__(64 * DE5_W, 2) void k_halfstep_de5(DevProb P, int h
     const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
     for (int x = tid; x < A; x += 64 * DE5_W) { const int ix = Lt[(size_t)x * P.RM + pl] - 1; xl[x] = nodes[ix]; wl[x] = weights[ix]; }
     for (int x = tid; x < B; x += 64 * DE5_W) { const int ix = Rt[(size_t)x * P.RM + qr] - 1; xr[x] = nodes[ix]; wr[x] = weights[ix]; }
-    for (int x = B + tid; x < B + 16; x += 64 * DE5_W) xr[x] = 1.0;            // the division batches of four may run past B
+    for (int x = B + tid; x < B + DE5_SEG; x += 64 * DE5_W) xr[x] = 1.0;       // the division batches of eight may run past B
     for (int x = tid; x <= A; x += 64 * DE5_W) UL[x] = ULg[x];
     box[tid] = DE5_SENT;
     const int i1 = iscol ? (live ? vmode : 0) : cur.jj - 1, i2 = iscol ? cur.kk - 1 : (live ? vmode : 0);
     const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
     __syncthreads();
-    // segments of the body xr[0..B): SEG per wave (a multiple of 4), nact waves have work
-    const int SEG = (((B + DE5_W - 1) / DE5_W) + 3) & ~3;
-    const int nact = (B > 0) ? (B + SEG - 1) / SEG : 1;
+    // the body xr[0..B) of a row in segments of 16 columns, dealt round robin to nact waves; R rounds per row
+    const int nact = max(1, min(DE5_W, (B + DE5_SEG - 1) / DE5_SEG));
     if (wv >= nact) return;                                   // no barrier below this line
-    const int jlo = wv * SEG, cnt = (B > 0) ? min(SEG, B - jlo) : 0;
+    const int R = (B > 0) ? (B + nact * DE5_SEG - 1) / (nact * DE5_SEG) : 1;
     unsigned long long *mybox = box + (size_t)wv * 64, *nextbox = box + (size_t)((wv + 1 == nact) ? 0 : wv + 1) * 64;
     double a = 1.0;
     WStream sl, sr;
@@ -380,34 +383,40 @@ __global__ __launch_bounds__(64 * DE5_W, 2) void k_halfstep_de5(DevProb P, int h
         const double uh = hasx1 ? UL[i] * x1 : 1.0;
         const double u2 = uh * x2;
         double u = u2;
-        if (jlo > 0) u = lds_chain(u, xr, jlo);              // the row's running product up to my segment
-        double f[DE5_SEG];
+        if (wv > 0) u = lds_chain(u, xr, wv * DE5_SEG);     // the row's running product up to my first segment
+        for (int r = 0; r < R; r++) {
+            const int j0 = (r * nact + wv) * DE5_SEG, cnt = max(0, min(DE5_SEG, B - j0));
+            double f[DE5_SEG];
+            if (cnt > 0) {                                    // wave-uniform; xr reads as 1.0 from B to B + DE5_SEG
 #pragma unroll
-        for (int kc = 0; kc < DE5_SEG / 4; kc++) {
-            if (4 * kc < cnt) {                               // wave-uniform
-                const double *xp = xr + jlo + 4 * kc;
-                const double ua = u * xp[0], ub = ua * xp[1], uc = ub * xp[2], ud = uc * xp[3];
-                f[4 * kc] = de_t2<FAST>(ua); f[4 * kc + 1] = de_t2<FAST>(ub); f[4 * kc + 2] = de_t2<FAST>(uc); f[4 * kc + 3] = de_t2<FAST>(ud);
-                u = ud;
-            }
-        }
-        if (wv == 0) {
-            const double t1 = hasx1 ? de_t2<FAST>(uh) : 1.0, t2 = de_t2<FAST>(u2);
-            if (i > 0 && nact > 1 && !de5_recv(mybox, lane, a, &giveup)) DE5_FAIL();
-            if (hasx1) { a = sl.chain(a, A - i, lane); a = a * t1; }
-            a = a * t2;
-        } else if (!de5_recv(mybox, lane, a, &giveup)) DE5_FAIL();
+                for (int b8 = 0; b8 < DE5_SEG / 8; b8++) {
+                    if (8 * b8 < cnt) {
+                        double ua[8], fa[8];
 #pragma unroll
-        for (int kc = 0; kc < DE5_SEG / 4; kc++) {
-            if (4 * kc + 4 <= cnt) { a = a * f[4 * kc]; a = a * f[4 * kc + 1]; a = a * f[4 * kc + 2]; a = a * f[4 * kc + 3]; }
-            else if (4 * kc < cnt) {
-                const int rem = cnt - 4 * kc;
-                a = a * f[4 * kc];
-                if (rem > 1) a = a * f[4 * kc + 1];
-                if (rem > 2) a = a * f[4 * kc + 2];
+                        for (int k = 0; k < 8; k++) { u = u * xr[j0 + 8 * b8 + k]; ua[k] = u; }
+                        de_t2xw<FAST, 8>(ua, fa);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) f[8 * b8 + k] = fa[k];
+                    }
+                }
             }
+            if (wv == 0 && r == 0) {
+                const double t1 = hasx1 ? de_t2<FAST>(uh) : 1.0, t2 = de_t2<FAST>(u2);
+                if (i > 0 && nact > 1 && !de5_recv(mybox, lane, a, &giveup)) DE5_FAIL();
+                if (hasx1) { a = sl.chain(a, A - i, lane); a = a * t1; }
+                a = a * t2;
+            } else if (nact > 1 && !de5_recv(mybox, lane, a, &giveup)) DE5_FAIL();
+            if (cnt == DE5_SEG) {
+#pragma unroll
+                for (int k = 0; k < DE5_SEG; k++) a = a * f[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < DE5_SEG; k++) if (k < cnt) a = a * f[k];
+            }
+            if (nact > 1) de5_send(nextbox, lane, a);
+            // over the other waves' segments to my next one (only if there is one)
+            if (r + 1 < R && cnt == DE5_SEG && nact > 1) u = lds_chain(u, xr + j0 + DE5_SEG, (nact - 1) * DE5_SEG);
         }
-        if (nact > 1) de5_send(nextbox, lane, a);
     }
     if (wv != 0) return;
     if (nact > 1 && !de5_recv(mybox, lane, a, &giveup)) DE5_FAIL();
