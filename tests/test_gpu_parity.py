@@ -424,7 +424,8 @@ def _full(cores):
     return t.reshape(t.shape[1:-1])
 
 
-@pytest.mark.parametrize("m,n,r,piv,ng", [(6, 33, 12, 2, 1), (10, 25, 16, 2, 1), (7, 9, 8, 2, 3)])
+@pytest.mark.parametrize("m,n,r,piv,ng", [(6, 33, 12, 2, 1), (10, 25, 16, 2, 1), (7, 9, 8, 2, 3), (9, 51, 32, 2, 1)],
+                         ids=["c6", "c10", "c7_3groups", "c9_r32_tsqr"])     # the last: 1632 x 32 unfoldings, tall-skinny QR over several workgroups
 def test_tt_ort_svd_norm_dot(m, n, r, piv, ng):
     """N1 (A12/A13): dtt_ort / dtt_svd / dtt_norm / dtt_dot / dtt_ijk on the device against the oracle's restatement
     and the GENUINE reference's numbers (tests/golden/ttops_*.txt).  Floating point: LAPACK's QR/SVD are restated

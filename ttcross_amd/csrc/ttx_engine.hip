@@ -1782,8 +1782,56 @@ static int gemm(ttx_engine *h, int M, int N, int K, const double *A, int lda, co
     hipLaunchKernelGGL(k_gemm_mfma, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, h->stream, M, N, K, A, lda, B, ldb, C, ldc);
     return TTX_OK;
 }
+// Tall-skinny QR of A (m x n, m >> n) over several workgroups (ttx_ttops.h): levels of LDS-resident panel factorisations, then
+// the explicit Q from the top level down.  Scratch: Wb (Q panels of level 0), Wc (stacked triangles of the levels / their
+// accumulated Q), Wd (Q panels of the levels >= 1) -- all free while a qr() is running.  false: shape not eligible.
+static bool qr_tsqr(ttx_engine *h, int m, int n, double *A, double *R, double *tau, int *rc_out)
+{
+    *rc_out = TTX_OK;
+    if (A != h->Wa || n > 96 || m < 4 * n || (getenv("TTX_TSQR") && atoi(getenv("TTX_TSQR")) == 0)) return false;
+    const size_t budget = 150 * 1024 / sizeof(double);
+    const int RB = (int)((budget - 2 * n - 2) / (size_t)(n + 1));            // rows of a panel that fits with its reflector
+    if (RB < 2 * n) return false;
+    struct Lvl { int rows, P, rbs; double *M, *Q; };
+    std::vector<Lvl> lv;
+    double *Sbuf = h->Wc, *Tbuf = h->Wd;
+    int rows = m; double *M = A;
+    while ((size_t)rows * n + rows + n + 4 > budget) {                          // until one workgroup's LDS takes the rest
+        const int P = (rows + RB - 1) / RB, rbs = (rows + P - 1) / P;
+        if (rows - (P - 1) * rbs < n) return false;                             // a last panel shorter than n: keep the one-workgroup path
+        Lvl L{rows, P, rbs, M, lv.empty() ? h->Wb : Tbuf};
+        if (!lv.empty()) Tbuf += (size_t)rows * n;
+        lv.push_back(L);
+        M = Sbuf; Sbuf += (size_t)P * n * n; rows = P * n;
+    }
+    if (lv.empty()) return false;
+    static size_t a_qp = 0, a_q1 = 0;
+    for (size_t l = 0; l < lv.size(); l++) {
+        const Lvl &L = lv[l];
+        double *Rst = (l + 1 < lv.size()) ? lv[l + 1].M : M;                    // the next level's matrix (P n x n)
+        const size_t lds = sizeof(double) * qr_panel_lds_doubles(L.rbs, n);
+        if ((*rc_out = ensure_lds(reinterpret_cast<const void *>(k_qr_panel), lds, a_qp))) return true;
+        hipLaunchKernelGGL(k_qr_panel, dim3(L.P), dim3(1024), lds, h->stream, L.rows, n, L.rbs, L.M, L.Q, Rst, L.P * n);
+    }
+    {   // top: one workgroup, in place: M -> Q_top (rows x n), R (n x n)
+        const size_t lds_all = sizeof(double) * ((size_t)rows + n + 4 + (size_t)rows * n);
+        if ((*rc_out = ensure_lds(reinterpret_cast<const void *>(k_qr<true>), lds_all, a_q1))) return true;
+        hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(1024), lds_all, h->stream, rows, n, M, R, tau);
+    }
+    // explicit Q, top down: Qacc(level l) = blockdiag(Q_p) * Qacc(level l+1); level l's own matrix buffer takes the result
+    const double *Qup = M; int ldup = rows;
+    for (int l = (int)lv.size() - 1; l >= 0; l--) {
+        const Lvl &L = lv[l];
+        double *out = L.M;                                                      // level 0: A itself
+        hipLaunchKernelGGL(k_gemm_mfma_panels, dim3((n + 63) / 64, (L.rbs + 15) / 16, L.P), dim3(256), 0, h->stream,
+                           L.rows, n, L.rbs, (const double *)L.Q, L.rows, Qup, ldup, out, L.rows);
+        Qup = out; ldup = L.rows;
+    }
+    return true;
+}
 static int qr(ttx_engine *h, int m, int n, double *A, double *R, double *tau)
 {
+    { int rc = TTX_OK; if (qr_tsqr(h, m, n, A, R, tau, &rc)) return rc; }
     const size_t lds = sizeof(double) * ((size_t)m + n + 4);
     if (lds > 150 * 1024) return fail(TTX_EINVAL, "dtt_ort: unfolding with %d rows does not fit the LDS-staged reflector", m);
     // small unfoldings are factored entirely inside LDS; larger ones stream the panel from L2 with threads mapped to rows
@@ -1796,6 +1844,15 @@ static int qr(ttx_engine *h, int m, int n, double *A, double *R, double *tau)
         if (int rc = ensure_lds(reinterpret_cast<const void *>(k_qr<false>), lds, a_q0)) return rc;
         hipLaunchKernelGGL(k_qr<false>, dim3(1), dim3(1024), lds, h->stream, m, n, A, R, tau);
     }
+    return TTX_OK;
+}
+static int jacobi(ttx_engine *h, int p, int q, double *X, double *V, double *sv, int *perm, int *info, double tol, int rmax)
+{
+    const size_t lds = sizeof(double) * ((size_t)p + q) * q;
+    const int in_lds = lds <= 140 * 1024;
+    static size_t a_j = 0;
+    if (in_lds) { if (int rc = ensure_lds(reinterpret_cast<const void *>(k_jacobi_svd), lds, a_j)) return rc; }
+    hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(1024), in_lds ? lds : 0, h->stream, p, q, X, V, sv, perm, info, 1, tol, rmax, in_lds);
     return TTX_OK;
 }
 static int sumsq(ttx_engine *h, size_t n, const double *x, double *out_host)
@@ -1858,7 +1915,7 @@ static int svd_impl(ttx_engine *h, double tol, int rmax)
             //   =>  A = (Q Ub S) Vb^T: Q Ub S goes into the previous core, Vb^T is the new core
             hipLaunchKernelGGL(k_pack_core, g1((size_t)mm * nn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, mm, n, r[k], RM, SS, 0);
             if ((rc = qr(h, mm, nn, h->Wa, Rm, tau))) return rc;        // Wa -> Q (mm x nn), Rm = R (nn x nn)
-            hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(1024), 0, h->stream, nn, nn, Rm, Vb, sv, perm, info, 1, tol, rmax);
+            if ((rc = jacobi(h, nn, nn, Rm, Vb, sv, perm, info, tol, rmax))) return rc;
             int inf2[2];
             HIPCHECK(hipMemcpyAsync(inf2, info, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(hipMemcpyAsync(svh.data(), sv, sizeof(double) * nn, hipMemcpyDeviceToHost, h->stream));
@@ -1881,7 +1938,7 @@ static int svd_impl(ttx_engine *h, double tol, int rmax)
         hipLaunchKernelGGL(k_pack_core, g1((size_t)mm * nn), dim3(256), 0, h->stream, core_dev(h, k), h->Wa, mm, n, r[k], RM, SS, 1);
         if ((rc = qr(h, nn, mm, h->Wa, Rm, tau))) return rc;            // Wa -> Q1 (nn x mm), Rm = R1 (mm x mm)
         hipLaunchKernelGGL(k_transpose, g1((size_t)mm * mm), dim3(256), 0, h->stream, mm, mm, Rm, Rt);
-        hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(1024), 0, h->stream, mm, mm, Rt, Vb, sv, perm, info, 1, tol, rmax);
+        if ((rc = jacobi(h, mm, mm, Rt, Vb, sv, perm, info, tol, rmax))) return rc;
         int inf[2];
         HIPCHECK(hipMemcpyAsync(inf, info, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(hipMemcpyAsync(svh.data(), sv, sizeof(double) * mm, hipMemcpyDeviceToHost, h->stream));

@@ -160,6 +160,92 @@ __global__ __launch_bounds__(1024) void k_qr(int m, int n, double *Ag, double *R
     if (INLDS) { for (size_t x = tid; x < (size_t)m * mn; x += nt) Ag[x] = A[x]; }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Tall-skinny QR (TSQR) for unfoldings that do not fit one CU's LDS (round 2): the rows are cut into panels of `rbs` rows,
+// every panel is factored by its own workgroup ENTIRELY IN LDS (k_qr_panel, the arithmetic of k_qr<true>), the n x n
+// triangles are stacked and factored again (recursively, host loop in qr_tsqr), and the explicit Q of a level is the
+// product of its panels' Q with the n x n blocks of the level above (k_gemm_mfma_panels, fp64 MFMA).  One dependent
+// single-workgroup pass over a 1632 x 32 unfolding streamed from L2 took 1.5 ms; the panels take ~0.1 ms side by side.
+// Block p: rows [p rbs, p rbs + mp) of M (rows x n, leading dimension rows) -> Q_p in Qout (same layout), R_p (n x n, zeros
+// below the diagonal) in rows [p n, p n + n) of Rst (leading dimension ldr).  The host guarantees mp >= n.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_qr_panel(int rows, int n, int rbs, const double *M, double *Qout, double *Rst, int ldr)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int p = blockIdx.x, r0 = p * rbs, m = min(rbs, rows - r0);
+    double *vsh = sm;                 // rbs
+    double *wsh = sm + rbs;           // n
+    double *tauv = wsh + n;           // n
+    double *A = sm + ((rbs + 2 * n + 1) & ~1);
+    __shared__ double red[16];
+    __shared__ double s_tau, s_beta, s_scale;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (size_t x = tid; x < (size_t)m * n; x += nt) { const int r = (int)(x % m), c = (int)(x / m); A[x] = M[r0 + r + (size_t)rows * c]; }
+    __syncthreads();
+    for (int i = 0; i < n; i++) {
+        double *x = A + i + (size_t)m * i;
+        const int len = m - i;
+        double q = 0.0;
+        for (int r = 1 + tid; r < len; r += nt) q += x[r] * x[r];
+        const double xn2 = tt_block_sum(q, red);
+        if (tid == 0) {
+            const double alpha = x[0], xn = sqrt(xn2);
+            if (xn == 0.0) { s_tau = 0.0; s_beta = alpha; s_scale = 0.0; }
+            else {
+                const double beta = -copysign(hypot(alpha, xn), alpha);
+                s_tau = (beta - alpha) / beta; s_beta = beta; s_scale = 1.0 / (alpha - beta);
+            }
+            tauv[i] = s_tau;
+        }
+        __syncthreads();
+        for (int r = tid; r < len; r += nt) { double v = (r == 0) ? 1.0 : x[r] * s_scale; vsh[r] = v; if (r > 0) x[r] = v; }
+        __syncthreads();
+        if (tid == 0) x[0] = s_beta;
+        qr_apply_reflector_cols(A, m, i, len, i + 1, n, s_tau, vsh, wsh);
+    }
+    __syncthreads();
+    for (int x = tid; x < n * n; x += nt) { const int r = x % n, c = x / n; Rst[(size_t)p * n + r + (size_t)ldr * c] = (r <= c) ? A[r + (size_t)m * c] : 0.0; }
+    __syncthreads();
+    for (int i = n - 1; i >= 0; i--) {                     // dorg2r
+        double *x = A + i + (size_t)m * i;
+        const int len = m - i;
+        const double tau = tauv[i];
+        for (int r = tid; r < len; r += nt) vsh[r] = (r == 0) ? 1.0 : x[r];
+        __syncthreads();
+        qr_apply_reflector_cols(A, m, i, len, i + 1, n, tau, vsh, wsh);
+        for (int r = tid; r < len; r += nt) x[r] = (r == 0) ? 1.0 - tau : -tau * vsh[r];
+        for (int r = tid; r < i; r += nt) A[r + (size_t)m * i] = 0.0;
+        __syncthreads();
+    }
+    for (size_t x = tid; x < (size_t)m * n; x += nt) { const int r = (int)(x % m), c = (int)(x / m); Qout[r0 + r + (size_t)rows * c] = A[x]; }
+}
+__host__ __device__ inline size_t qr_panel_lds_doubles(int rbs, int n) { return (size_t)((rbs + 2 * n + 1) & ~1) + (size_t)rbs * n; }
+
+// C_p (mp x n) = A_p (mp x n) * B_p (n x n) for the panels p = blockIdx.z of a level: A_p = rows [p rbs, ..) of A (lda), B_p = rows
+// [p n, p n + n) of B (ldb), C_p = rows [p rbs, ..) of C (ldc); one wave per 16 x 16 tile, v_mfma_f64_16x16x4_f64 as in k_gemm_mfma
+__global__ __launch_bounds__(256) void k_gemm_mfma_panels(int rows, int n, int rbs, const double *A, int lda, const double *B, int ldb, double *C, int ldc)
+{
+    const int p = blockIdx.z, r0 = p * rbs, M = min(rbs, rows - r0);
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int tm = blockIdx.y * 16, tn = (blockIdx.x * 4 + wave) * 16;
+    if (tn >= n || tm >= M) return;
+    const double *Ap = A + r0, *Bp = B + (size_t)p * n;
+    double *Cp = C + r0;
+    const int ar = tm + (l & 15), bc = tn + (l & 15), kq = l >> 4;
+    dbl4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < n; k0 += 4) {
+        const int k = k0 + kq;
+        const double a = (ar < M && k < n) ? Ap[ar + (size_t)lda * k] : 0.0;
+        const double b = (bc < n && k < n) ? Bp[k + (size_t)ldb * bc] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int row = tm + (l >> 4) + 4 * reg, col = tn + (l & 15);
+        if (row < M && col < n) Cp[row + (size_t)ldc * col] = acc[reg];
+    }
+}
+
 // C (M x N, ldc) = A (M x K, lda) * B (K x N, ldb), fp64 on the matrix cores: one wave per 16x16 tile of C,
 // v_mfma_f64_16x16x4_f64 per k-step of 4.  Operand lane maps (cdna_hip_programming.md sec. 3): A[row l&15][k l>>4],
 // B[k l>>4][col l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
@@ -238,13 +324,39 @@ __global__ void k_scal_core(double *core, int r0, int n, int r1, int RM, size_t 
 // ordering (perm[j] = column holding the j-th largest singular value) and the reference's chop (lib/mat.f90:433-458)
 // info[0] = kept rank rr, info[1] = sweeps; sout[q] sorted singular values; one 1024-thread workgroup, the
 // q/2 disjoint column pairs of a round-robin round rotate concurrently.
-__global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *X, double *V, double *sout, int *perm, int *info,
-                                                     int has_tol, double tol, int rmax)
+// sum over the tpp (16, 32 or 64) consecutive lanes of a pair's thread group on the DPP data path (ttx_kernels.h is included
+// before this header): quad butterflies, two row rotations, then the row broadcasts -- a __shfl_xor of a double is two
+// ds_bpermute round trips, 36 of them in sequence per rotation round made a round last ~2.8 us
+__device__ __forceinline__ double jac_group_sum(double v, int tpp, int lane)
 {
+    v = v + dpp_d<0xb1, 0xf>(v);
+    v = v + dpp_d<0x4e, 0xf>(v);
+    v = v + dpp_d<0x124, 0xf>(v);
+    v = v + dpp_d<0x128, 0xf>(v);                          // every lane: a sum of its row of 16 (association differs from quad to quad)
+    if (tpp == 16)                                          // one value for the whole group: lane 15's
+        return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x15f, 0xf, 0xf, false));
+    v = v + dpp_d<0x142, 0xa>(v);                          // rows 1 and 3: + the row before
+    if (tpp == 32) {
+        const double lo = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), 31) << 32) |
+                                               (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(v), 31));
+        const double hi = readlane63(v);
+        return lane < 32 ? lo : hi;
+    }
+    v = v + dpp_d<0x143, 0xc>(v);                          // rows 2 and 3: + the first half
+    return readlane63(v);
+}
+// in_lds: X and V live in dynamic LDS ((p + q) q doubles) for the whole iteration -- a rotation round is a dependent chain of
+// column reads, a reduction and column writes, ~3.5 us per round out of L2 (0.9 ms for a 32 x 32 matrix), a tenth of that in LDS
+__global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *Xg, double *Vg, double *sout, int *perm, int *info,
+                                                     int has_tol, double tol, int rmax, int in_lds)
+{
+    extern __shared__ __align__(16) double jsm[];
     __shared__ int s_rot;
     __shared__ double ssh[256];
     __shared__ int psh[256];
     const int tid = threadIdx.x, nt = blockDim.x;
+    double *X = in_lds ? jsm : Xg, *V = in_lds ? jsm + (size_t)p * q : Vg;
+    if (in_lds) for (int x = tid; x < p * q; x += nt) X[x] = Xg[x];
     for (int x = tid; x < q * q; x += nt) V[x] = ((x % q) == (x / q)) ? 1.0 : 0.0;
     __syncthreads();
     const int qq = (q + 1) & ~1;                 // players of the tournament (one dummy if q is odd)
@@ -268,7 +380,8 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *X, do
                         double *xa = X + (size_t)p * a, *xb = X + (size_t)p * b;
                         double al = 0.0, be = 0.0, ga = 0.0;
                         for (int i = sub; i < p; i += tpp) { double u = xa[i], w = xb[i]; al += u * u; be += w * w; ga += u * w; }
-                        for (int o = tpp >> 1; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
+                        if (tpp >= 16) { al = jac_group_sum(al, tpp, tid & 63); be = jac_group_sum(be, tpp, tid & 63); ga = jac_group_sum(ga, tpp, tid & 63); }
+                        else for (int o = tpp >> 1; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
                         if (!(fabs(ga) <= 1e-16 * sqrt(al * be) || ga == 0.0)) {
                             if (sub == 0) atomicAdd(&s_rot, 1);
                             const double zeta = (be - al) / (2.0 * ga);
@@ -297,6 +410,10 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *X, do
         if (s > 0.0) for (int i = tid & 63; i < p; i += 64) xj[i] /= s;
     }
     __syncthreads();
+    if (in_lds) {
+        for (int x = tid; x < p * q; x += nt) Xg[x] = X[x];
+        for (int x = tid; x < q * q; x += nt) Vg[x] = V[x];
+    }
     if (tid == 0) {
         for (int j = 0; j < q; j++) psh[j] = j;
         for (int j = 0; j < q - 1; j++) {               // selection sort, descending
