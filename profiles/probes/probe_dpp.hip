@@ -167,6 +167,18 @@ __global__ __launch_bounds__(64) void k_fma3(int reps, double *out, double *sink
     sink[lane] = acc;
 }
 
+// (6) shader clock while a launch of `blocks` single-wave workgroups runs a dependent fp64 chain for ~ms: core-clock counter
+//     (s_memtime) against the constant 100 MHz counter (s_memrealtime)
+__global__ __launch_bounds__(64) void k_clock(int iters, double *out, double *sink)
+{
+    double a = 1.0 + 1e-9 * threadIdx.x;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; i++) a = __builtin_fma(a, 1.0000001, 1e-9);
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = (double)(c1 - c0) / ((double)(w1 - w0) * 10.0); out[1] = (double)(w1 - w0) * 10.0 / iters; }
+    sink[blockIdx.x * 64 + threadIdx.x] = a;
+}
+
 int main()
 {
     const int NB = 512, N = NB * 16;
@@ -217,6 +229,11 @@ int main()
         hipLaunchKernelGGL(k_fma3, dim3(1), dim3(64), 0, 0, 2000, out, sink);
         CK(hipMemcpy(o, out, 16, hipMemcpyDeviceToHost));
         printf("one wave, 8 independent streams: fma(v,v,v) %.2f ns per instruction, fma(-v,v,1.0) %.2f ns\n", o[0], o[1]);
+    }
+    for (int blocks : {1, 64, 200, 1024, 8192}) {
+        for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(64), 0, 0, 400000, out, sink);
+        CK(hipMemcpy(o, out, 16, hipMemcpyDeviceToHost));
+        printf("shader clock with %4d single-wave workgroups in flight: %.2f GHz (dependent fma: %.2f ns)\n", blocks, o[0], o[1]);
     }
     CK(hipDeviceSynchronize());
     return 0;
