@@ -109,7 +109,7 @@ def test_soak_repeated_runs_are_identical():
     """The same engine run again and again (cluster kernel: its record tags and barrier counters carry over between
     launches) must return the identical integral and evaluation count every time."""
     runs = int(os.environ.get("TTX_SOAK_RUNS", "25"))
-    for kind, m, n, r, piv, ng in [("c", 64, 51, 32, 2, 8), ("c", 20, 17, 24, 3, 3), ("d", 8, 17, 8, 2, 2)]:
+    for kind, m, n, r, piv, ng in [("c", 64, 51, 32, 2, 8), ("c", 20, 17, 24, 3, 3), ("d", 8, 17, 8, 2, 2), ("d", 60, 9, 6, 2, 3)]:
         s = _setup(kind, m, n)
         tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng)
         ref = None
