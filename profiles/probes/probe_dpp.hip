@@ -179,6 +179,30 @@ __global__ __launch_bounds__(64) void k_clock(int iters, double *out, double *si
     sink[blockIdx.x * 64 + threadIdx.x] = a;
 }
 
+// (7) latency of DEPENDENT fp64 operations whose second operand comes from a register array (one wave): add, mul, fma(x, 1.0, acc)
+//     (= the same sum with one rounding), fma with a register multiplier
+template <int OP>
+__global__ __launch_bounds__(64) void k_dep(int reps, const double *g, double *out, double *sink)
+{
+    double x[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) x[q] = g[q * 64 + threadIdx.x];
+    double a = (OP == 1) ? 1.0 : 0.0;
+    const long long t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            if (OP == 0) a = a + x[q];
+            if (OP == 1) a = a * x[q];
+            if (OP == 2) a = __builtin_fma(x[q], 1.0, a);
+            if (OP == 3) a = __builtin_fma(x[q], x[(q + 1) & 31], a);
+        }
+    }
+    const long long t1 = wall_clock64();
+    if (threadIdx.x == 0) out[0] = 10.0 * (double)(t1 - t0) / (32.0 * reps);
+    sink[threadIdx.x] = a;
+}
+
 int main()
 {
     const int NB = 512, N = NB * 16;
@@ -229,6 +253,16 @@ int main()
         hipLaunchKernelGGL(k_fma3, dim3(1), dim3(64), 0, 0, 2000, out, sink);
         CK(hipMemcpy(o, out, 16, hipMemcpyDeviceToHost));
         printf("one wave, 8 independent streams: fma(v,v,v) %.2f ns per instruction, fma(-v,v,1.0) %.2f ns\n", o[0], o[1]);
+    }
+    {
+        const char *nm[4] = {"a + x", "a * x", "fma(x, 1.0, a)", "fma(x, y, a)"};
+        auto run = [&](auto kern, int op) {
+            hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, 0, 2000, g, out, sink);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, 0, 2000, g, out, sink);
+            CK(hipMemcpy(o, out, 8, hipMemcpyDeviceToHost));
+            printf("one wave, dependent %-16s with register operands: %.2f ns per operation\n", nm[op], o[0]);
+        };
+        run(k_dep<0>, 0); run(k_dep<1>, 1); run(k_dep<2>, 2); run(k_dep<3>, 3);
     }
     for (int blocks : {1, 64, 200, 1024, 8192}) {
         for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(64), 0, 0, 400000, out, sink);

@@ -64,6 +64,101 @@ __device__ __forceinline__ double mvn_quadform_wave(int m, const double *dv, int
     return ex;
 }
 
+// The same for m a multiple of 64 WITHOUT LDS (round 2, later).  Stamps inside mvn_quadform_wave: 0.29 us per row for the S loads
+// and the 128 terms, 0.9-1.1 us for adding them -- 7-8.4 ns per term although a dependent v_add_f64 takes 2.4 ns: the LDS
+// broadcast reads are the cost (a ds_read2_b64 returns 1 KB to the wave and occupies the LDS return path ~32 cycles).  The terms
+// are computed one per lane anyway (lane l holds T_{64q+l}); here they STAY in that register and every add takes its operand
+// with two v_readlane_b32 into an SGPR pair (independent of the running sum) and a v_add_f64 with a scalar operand: three
+// VALU instructions per term, no LDS traffic, no barrier.  The per-lane term of the free dimension replaces lane L's at its place
+// in the order by a uniform select.  Operations and their order per lane are unchanged: bit-identical.
+__device__ __forceinline__ double mvn_lane(double x, int k)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, k), hi = __builtin_amdgcn_readlane((int)(b >> 32), k);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sixteen lane values at a time into scalar registers first (so that the reads run ahead of the dependent adds), then the adds;
+// kL: the lane whose term is replaced by `special` (-1: none) -- only the batch that contains it pays for the selects
+__device__ __forceinline__ double mvn_add64(double ex, double t, int kL, double special)
+{
+#pragma unroll
+    for (int b = 0; b < 64; b += 16) {
+        double sv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) sv[k] = mvn_lane(t, b + k);
+        if (kL >= b && kL < b + 16) {                      // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 16; k++) ex = ex + ((b + k == kL) ? special : sv[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) ex = ex + sv[k];
+        }
+    }
+    return ex;
+}
+// NQ = m / 64 as a template parameter: the body is unrolled over the NQ registers a lane holds of a row, and unrolled for the
+// largest possible count the kernel outgrew the instruction cache (measured: 2x slower half-steps)
+template <int NQ>
+__device__ __forceinline__ double mvn_quadform_lanes(int m, const double *dv, int L, double dL, const double *icT, int lane)
+{
+    double dreg[NQ], s0[NQ], s1[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int j = lane + 64 * q;
+        dreg[q] = dv[j];
+        s0[q] = icT[j];
+        s1[q] = icT[(size_t)m * (m > 1 ? 1 : 0) + j];
+    }
+    const int qL = L >> 6, kL = L & 63;
+    double ex = 0.0;
+    for (int i = 0; i < m; i++) {
+        double s2[NQ];
+        const double *row2 = icT + (size_t)m * (i + 2 < m ? i + 2 : m - 1);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) s2[q] = row2[lane + 64 * q];              // S two rows ahead
+        if (i != L) {
+            const double di = dv[i];
+            double special = 0.0;
+            if (L >= 0) {                              // S_iL sits in lane kL of this row's registers
+                double siL = 0.0;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) if (q == qL) siL = mvn_lane(s0[q], kL);
+                special = di * siL * dL;               // the free dimension: this lane's own difference
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const double t = di * s0[q] * dreg[q];                        // (d_i S_ij) d_j, j = 64 q + lane
+                ex = mvn_add64(ex, t, (L >= 0 && q == qL) ? kL : -1, special);
+            }
+        } else {
+            // the row of the free dimension: (d_L S_Lj) d_j per lane, S_Lj and d_j (j /= L) lane by lane
+            for (int j = 0; j < m; j++) {
+                double sj = 0.0, dj = 0.0;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) if (q == (j >> 6)) { sj = mvn_lane(s0[q], j & 63); dj = mvn_lane(dreg[q], j & 63); }
+                if (j == L) dj = dL;
+                ex = ex + dL * sj * dj;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { s0[q] = s1[q]; s1[q] = s2[q]; }
+    }
+    return ex;
+}
+__device__ __forceinline__ double mvn_quadform(int m, const double *dv, int L, double dL, const double *icT, double *tb, int lane)
+{
+    if ((m & 63) == 0) {
+        switch (m >> 6) {
+            case 1: return mvn_quadform_lanes<1>(m, dv, L, dL, icT, lane);
+            case 2: return mvn_quadform_lanes<2>(m, dv, L, dL, icT, lane);
+            case 3: return mvn_quadform_lanes<3>(m, dv, L, dL, icT, lane);
+            case 4: return mvn_quadform_lanes<4>(m, dv, L, dL, icT, lane);
+            default: break;
+        }
+    }
+    return mvn_quadform_wave(m, dv, L, dL, icT, tb, lane);
+}
+
 // grid = (RM * ceil(NM/64) wave slots, groups), 64 threads.  Same contract as k_halfstep (modes 0, 1, 2).
 __global__ __launch_bounds__(64) void k_halfstep_mvn(DevProb P, int h, int dir, int mode)
 {
@@ -113,7 +208,7 @@ __global__ __launch_bounds__(64) void k_halfstep_mvn(DevProb P, int h, int dir, 
     }
     const double dL = nodes[live ? vmode : 0] - mu[L];
     __syncthreads();
-    const double ex = mvn_quadform_wave(m, dv, L, dL, P.auxT, tb, lane);
+    const double ex = mvn_quadform(m, dv, L, dL, P.auxT, tb, lane);
     const double a = ttx_exp(-0.5 * ex) / P.mvn_norm;                  // lib/mvn_pdf.f90:82
     // ---- fiber store, amax, residual, arg-max: as k_halfstep, on the fiber's linear index t ----
     const int u_ = iscol ? pv : vmode, v_ = iscol ? vmode : pv;
@@ -167,6 +262,6 @@ __global__ __launch_bounds__(64) void k_lottery_eval_mvn(DevProb P)
         dv[x] = nodes[ix] - mu[x];
     }
     __syncthreads();
-    const double ex = mvn_quadform_wave(m, dv, -1, 0.0, P.auxT, tb, lane);
+    const double ex = mvn_quadform(m, dv, -1, 0.0, P.auxT, tb, lane);
     if (lane == 0) P.lotf[(size_t)g * P.lot_max + il] = ttx_exp(-0.5 * ex) / P.mvn_norm;
 }
