@@ -77,22 +77,42 @@ __device__ __forceinline__ double mvn_lane(double x, int k)
     const int lo = __builtin_amdgcn_readlane((int)b, k), hi = __builtin_amdgcn_readlane((int)(b >> 32), k);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-// sixteen lane values at a time into scalar registers first (so that the reads run ahead of the dependent adds), then the adds;
-// kL: the lane whose term is replaced by `special` (-1: none) -- only the batch that contains it pays for the selects
-__device__ __forceinline__ double mvn_add64(double ex, double t, int kL, double special)
+// sixteen lane values at a time into scalar registers first (so that the reads run ahead of the dependent adds), then the adds.
+// The term of lane kL is replaced by `special`: the batch of sixteen that contains it (BL, a template parameter: one straight
+// line of code per position, chosen by ONE wave-uniform branch per row) pays for the selects; a branch per batch instead kept the
+// lane reads of a batch from running under the adds of the batch before (measured: 0.4 us per row of 128 terms).
+template <int BL>
+__device__ __forceinline__ double mvn_add64_at(double ex, double t, int kLL, double special)
 {
 #pragma unroll
     for (int b = 0; b < 64; b += 16) {
         double sv[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) sv[k] = mvn_lane(t, b + k);
-        if (kL >= b && kL < b + 16) {                      // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 16; k++) ex = ex + ((b + k == kL) ? special : sv[k]);
-        } else {
+        for (int k = 0; k < 16; k++) ex = ex + ((b == 16 * BL && k == kLL) ? special : sv[k]);
+    }
+    return ex;
+}
+__device__ __forceinline__ double mvn_add64(double ex, double t, int kL, double special)
+{
+    switch (kL >> 4) {                                      // wave-uniform
+        case 0: return mvn_add64_at<0>(ex, t, kL & 15, special);
+        case 1: return mvn_add64_at<1>(ex, t, kL & 15, special);
+        case 2: return mvn_add64_at<2>(ex, t, kL & 15, special);
+        default: return mvn_add64_at<3>(ex, t, kL & 15, special);
+    }
+}
+// the same without a replaced lane: no branch between the batches, so the lane reads of a batch run under the adds of the one before
+__device__ __forceinline__ double mvn_add64_plain(double ex, double t)
+{
 #pragma unroll
-            for (int k = 0; k < 16; k++) ex = ex + sv[k];
-        }
+    for (int b = 0; b < 64; b += 16) {
+        double sv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) sv[k] = mvn_lane(t, b + k);
+#pragma unroll
+        for (int k = 0; k < 16; k++) ex = ex + sv[k];
     }
     return ex;
 }
@@ -128,10 +148,11 @@ __device__ __forceinline__ double mvn_quadform_lanes(int m, const double *dv, in
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const double t = di * s0[q] * dreg[q];                        // (d_i S_ij) d_j, j = 64 q + lane
-                ex = mvn_add64(ex, t, (L >= 0 && q == qL) ? kL : -1, special);
+                if (L >= 0 && q == qL) ex = mvn_add64(ex, t, kL, special);    // wave-uniform
+                else ex = mvn_add64_plain(ex, t);
             }
         } else {
-            // the row of the free dimension: (d_L S_Lj) d_j per lane, S_Lj and d_j (j /= L) lane by lane
+            // the row of the free dimension: (d_L S_Lj) d_j per lane, S_Lj and d_j (j /= L) lane by lane (once per element)
             for (int j = 0; j < m; j++) {
                 double sj = 0.0, dj = 0.0;
 #pragma unroll
