@@ -468,8 +468,10 @@ def main():
     if rank != 0:
         return
     path = tt.sweep_path()
-    kname = {"chain": "k_halfstep", "fused": "k_sweep_fused", "cluster": "k_sweep_cluster"}[path]
-    kdesc = {"chain": "k_halfstep (one rook half-step: fiber evaluation + residual + arg-max)",
+    # the chain path's half-step kernel by integrand: the wave-per-pivot kernels of Ising D/E and mvn, the generic one otherwise
+    chain_k = "k_halfstep_de" if (argv[0] == "ising" and argv[1] in ("d", "e")) else "k_halfstep_mvn" if argv[0] == "mvn" else "k_halfstep"
+    kname = {"chain": chain_k, "fused": "k_sweep_fused", "cluster": "k_sweep_cluster"}[path]
+    kdesc = {"chain": chain_k + " (one rook half-step: fiber evaluation + residual + arg-max)",
              "fused": "k_sweep_fused (whole sweep of a bond group in one workgroup; bytes = its rook half-steps)",
              "cluster": "k_sweep_cluster (whole sweep of a bond group by a cluster of workgroups; bytes = its rook half-steps)"}[path]
     traffic = None
