@@ -98,6 +98,9 @@ struct WStream {
     }
 };
 
+#ifndef DE_RUNW
+#define DE_RUNW 8        // division chains interleaved per batch (16 measured 1 % faster on D_256: not worth the registers)
+#endif
 // the bond-spanning tail of a row: pair with s2 (x2), then with the right dims xr[0..B) (LDS, wave-uniform), eight pairs
 // at a time: running products, the eight divisions stage by stage (de_t2xw), then the factors into `a` in order
 template <bool FAST>
@@ -105,29 +108,29 @@ __device__ __forceinline__ void de_run(double &a, double u, double x2, const dou
 {
     u = u * x2; a = a * de_t2<FAST>(u);
     int j = 0;
-    if (B >= 8) {
-        double y[8];
+    if (B >= DE_RUNW) {
+        double y[DE_RUNW];
 #pragma unroll
-        for (int k = 0; k < 8; k++) y[k] = xr[k];
-        for (; j + 8 <= B; j += 8) {
-            double uu[8], t[8];
+        for (int k = 0; k < DE_RUNW; k++) y[k] = xr[k];
+        for (; j + DE_RUNW <= B; j += DE_RUNW) {
+            double uu[DE_RUNW], t[DE_RUNW];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { u = u * y[k]; uu[k] = u; }
-            if (j + 16 <= B) {                          // next batch's LDS reads fly under the divisions
+            for (int k = 0; k < DE_RUNW; k++) { u = u * y[k]; uu[k] = u; }
+            if (j + 2 * DE_RUNW <= B) {                 // next batch's LDS reads fly under the divisions
 #pragma unroll
-                for (int k = 0; k < 8; k++) y[k] = xr[j + 8 + k];
+                for (int k = 0; k < DE_RUNW; k++) y[k] = xr[j + DE_RUNW + k];
             }
-            de_t2xw<FAST, 8>(uu, t);
+            de_t2xw<FAST, DE_RUNW>(uu, t);
 #pragma unroll
-            for (int k = 0; k < 8; k++) a = a * t[k];
+            for (int k = 0; k < DE_RUNW; k++) a = a * t[k];
         }
     }
-    if (j + 4 <= B) {
+    for (; j + 4 <= B; j += 4) {
         const double u1 = u * xr[j], u2 = u1 * xr[j + 1], u3 = u2 * xr[j + 2], u4 = u3 * xr[j + 3];
         double t1, t2, t3, t4;
         de_t2x4<FAST>(u1, u2, u3, u4, t1, t2, t3, t4);
         a = a * t1; a = a * t2; a = a * t3; a = a * t4;
-        u = u4; j += 4;
+        u = u4;
     }
     for (; j < B; j++) { u = u * xr[j]; a = a * de_t2<FAST>(u); }
 }
