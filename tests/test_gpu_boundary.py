@@ -55,6 +55,42 @@ def test_host_callback_bit_exact_vs_oracle(userfun, d, n, r, piv, nproc):
     assert tt.quad(s["quad"]) == oo["value"]
 
 
+@pytest.mark.parametrize("name", ["ttx_test_userfun_nan", "ttx_test_userfun_partnan"])
+@pytest.mark.parametrize("piv,nproc", [(2, 1), (1, 3), (-1, 1), (0, 2)])
+def test_nan_integrand_neither_faults_nor_hangs(userfun, name, piv, nproc):
+    """An integrand that returns NaN (everywhere / on part of the domain): no arg-max comparison succeeds, and an index left at its
+    start value would address memory far outside the tables (found with an mvn normalisation that underflowed to 0: a GPU fault).
+    The searches now fall back to the first position, as the reference's idamax does; the run must end with finite or NaN numbers,
+    every pivot inside its ranges."""
+    import ctypes
+    lib, _ = userfun
+    addr = ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+    d, n, r = 5, 5, 4
+    x, w = D.lgwt(n)
+    par = np.concatenate([0.5 * (x + 1.0), 0.5 * w])
+    quad = [par[n:].copy()] * d
+    tt = E.TTCross([n] * d, E.TTX_FUN_HOST, [], r, pivoting=piv, accuracy=500 * D.EPS, quad=quad, nproc=nproc) if piv >= 0 else None
+    if tt is None:
+        pytest.skip("pivoting = -1 is not available with a host-evaluated fun")
+    tt.set_integrand_host(addr, par).run()
+    tp = tt.tapes()
+    assert tp.shape[0] >= 1
+    act = tp[:, 1:tt.d, :]
+    assert ((act == -1) | ((act >= 1) & (act <= max(n, r + 1)))).all()
+    assert all(1 <= rk <= r for rk in tt.ranks())
+    tt.close()
+
+
+def test_mvn_normalisation_that_underflows_is_refused():
+    """det of the covariance underflows to 0 at d = 300 (0.08^300): sqrt((2 pi)^d det) = 0 would make every value inf/NaN."""
+    import oracle_lib as O
+    s = D.box_setup("mvn", 300, 2)
+    s["aux"] = O.mvn_init(300)
+    assert s["aux"][300 + 300 * 300] == 0.0
+    with pytest.raises(E.TTXError, match="normalisation"):
+        E.TTCross(s["n"], s["fun_id"], s["par"], 2, pivoting=1, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"])
+
+
 def test_host_callback_accchk(userfun):
     _, addr = userfun
     s = _user_setup(5, 17)

@@ -105,7 +105,8 @@ EXP_CASES = [("stdnorm", 4, 33, 10, 2, 1), ("mvn", 6, 33, 12, 2, 1), ("stdnorm",
              ("mvn", 5, 9, 6, 0, 1), ("stdnorm", 5, 9, 5, -1, 1), ("mvn", 24, 17, 12, 2, 4), ("mvn-np", 20, 17, 12, 2, 2),
              ("mvn-np", 40, 17, 16, 2, 1),
              # d a multiple of 64: the quadratic form with register-resident terms (one, two and three registers of a row per lane)
-             ("mvn", 64, 5, 4, 2, 2), ("mvn", 128, 5, 5, 3, 3), ("mvn", 192, 3, 3, 1, 2)]
+             ("mvn", 64, 5, 4, 2, 2), ("mvn", 128, 5, 5, 3, 3), ("mvn", 192, 3, 3, 1, 2), ("mvn", 256, 3, 2, 1, 1),
+             ("mvn", 288, 2, 2, 1, 2)]       # not a multiple of 64: the LDS-broadcast sums with five registers of a row per lane
 
 
 @pytest.mark.parametrize("kind,d,n,r,piv,nproc", EXP_CASES, ids=[f"{c[0]}{c[1]}_n{c[2]}_r{c[3]}_p{c[4]}_np{c[5]}" for c in EXP_CASES])

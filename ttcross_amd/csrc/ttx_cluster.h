@@ -335,6 +335,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         amax = fmax(amax, ma);
         neval += nlot; rngpos += 2ull * nlot;
         sA0 = ttx_mulmod31(sA1, stepmul);
+        if (bi == INT_MAX) bi = 0;                       // every residual a NaN: the first candidate, as idamax
         int ii = lot[4 * bi], jj = lot[4 * bi + 1], kk = lot[4 * bi + 2], qq = lot[4 * bi + 3];
         double pivot = bv;
         CST(5);
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             n_resid += resid ? 1 : 0;
             done = dn;
             if (resid) {
+                if (ix == INT_MAX) ix = 0;
                 if (iscol) { const int i = ix % r0 + 1, j = ix / r0 + 1; done = havecol && haverow && (i == ii && j == jj); ii = i; jj = j; }
                 else       { const int k = ix % n2 + 1, q = ix / n2 + 1; done = havecol && haverow && (k == kk && q == qq); kk = k; qq = q; }
                 pivot = bb;

@@ -352,6 +352,12 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     if (cfg->fun_id == TTX_FUN_MVN) {
         if (cfg->naux < d + d * d + 1) { delete h; return fail(TTX_EINVAL, "mvn: aux too short"); }
         P.mvn_norm = std::sqrt(powi(2.0 * 3.141592653589793, d) * cfg->aux[d + (size_t)d * d]);   // lib/mvn_pdf.f90:82
+        if (!(P.mvn_norm > 0.0) || !std::isfinite(P.mvn_norm)) {
+            const double nrm = P.mvn_norm, det = cfg->aux[d + (size_t)d * d];
+            delete h;
+            return fail(TTX_EINVAL, "ttx_create: mvn normalisation sqrt((2 pi)^d det) = %g is not a positive finite number (det = %g under- or overflows at d = %d)",
+                        nrm, det, d);
+        }
     }
     P.SS = (size_t)h->RM * NM; P.SW = (size_t)NM * h->RM; P.CS = (size_t)h->RM * NM * h->RM;
     const size_t G = h->G, NC = h->NC, RM = h->RM;
@@ -1200,7 +1206,7 @@ static int run_impl(ttx_engine *h)
             if (nproc > 1) {
                 const size_t VSb = ((d + 7) & ~7) + 8;
                 const size_t lds_b = h->lds_par + 16 + sizeof(short) * 2 * VSb + sizeof(double) * (64 * 64 + 4) +
-                                     (P.bnd_wave ? sizeof(double) * (2 * (size_t)de_rows_stride(d) + 8) : 0);    // >= the 3 d doubles of the mvn corner
+                                     (P.bnd_wave ? sizeof(double) * (std::max<size_t>(2 * (size_t)de_rows_stride(d), 3 * (size_t)d + 2) + 8) : 0);    // D/E: two value rows; mvn: 3 d + 1 doubles
                 static size_t a_bnd = 0;
                 if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_exch_boundary<FUN>), lds_b, a_bnd)) return rc_;
                 if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), lds_b, st, Q); })) return rc_;

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(FB) void k_sweep_fused(DevProb P, int dir, int nste
         amax = fmax(amax, ma);
         fused_argmax(ba, bv, bi, sha, shv, shi);
         neval += nlot; rngpos += 2ull * nlot;
+        if (bi == INT_MAX) bi = 0;                       // every residual a NaN: the first candidate, as idamax
         int ii = lot[4 * bi], jj = lot[4 * bi + 1], kk = lot[4 * bi + 2], qq = lot[4 * bi + 3];
         double pivot = bv;
         // ---- rook half-steps (:516-582) / piv = 0 (:492-513) ----
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(FB) void k_sweep_fused(DevProb P, int dir, int nste
             done = dn;
             if (resid) {
                 fused_argmax(ab, bb, ix, sha, shv, shi);
+                if (ix == INT_MAX) ix = 0;
                 if (iscol) { const int i = ix % r0 + 1, j = ix / r0 + 1; done = havecol && haverow && (i == ii && j == jj); ii = i; jj = j; }
                 else       { const int k = ix % n2 + 1, q = ix / n2 + 1; done = havecol && haverow && (k == kk && q == qq); kk = k; qq = q; }
                 pivot = bb;

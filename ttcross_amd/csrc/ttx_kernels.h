@@ -599,6 +599,7 @@ __device__ inline void resolve_state(StepState &c, const Partial *pt)
         double a = pt[b].absmax; int ix = pt[b].idx;
         if (a > ba || (a == ba && ix < bi)) { ba = a; bv = pt[b].val; bi = ix; }
     }
+    if (bi == INT_MAX) bi = 0;      // nothing compared (every residual a NaN): the first position, as idamax returns (no wild index)
     if (c.pending == 1) {
         int i = bi % c.r0 + 1, j = bi / c.r0 + 1;
         c.done = c.havecol && c.haverow && (i == c.ii && j == c.jj);
@@ -666,6 +667,7 @@ __global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int n
         int hi = (gg + 1 == P.nprocs) ? snum : (int)((double)snum * (double)(gg + 1) / P.nprocs);
         gs.neval = (long long)nn * (hi - lo);
         if (g == 0) {
+            if (bi == INT_MAX) bi = 0;                            // every sample a NaN: the first one, as idamax
             int s = bi / nn, k = bi % nn + 1;
             for (int p = 1; p <= P.d; p++) P.ind0[p] = (k - 1 + s * (p - 1)) % P.n[p] + 1;   // :205-209
             P.ind0[P.d + 1] = 1;
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(256) void k_full_resolve(DevProb P)
     }
     block_argmax(ba, bv, bi, sha, shv, shi);
     if (tid == 0) {                                       // :388-396
-        int x = bi;
+        int x = (bi == INT_MAX) ? 0 : bi;                  // every residual a NaN: the first position, as idamax
         st.qq = x / (nf * st.n2) + 1; x %= nf * st.n2;
         st.kk = x / nf + 1; x %= nf;
         st.jj = x / st.r0 + 1; st.ii = x % st.r0 + 1;
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(256) void k_full_resolve2(DevProb P, int gx, int gy
     }
     block_argmax(ba, bv, bi, sha, shv, shi);
     if (tid == 0) {                                       // :388-396
-        int x = bi;
+        int x = (bi == INT_MAX) ? 0 : bi;                  // every residual a NaN: the first position, as idamax
         st.qq = x / (nf * st.n2) + 1; x %= nf * st.n2;
         st.kk = x / nf + 1; x %= nf;
         st.jj = x / st.r0 + 1; st.ii = x % st.r0 + 1;
@@ -1132,7 +1134,8 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         LotPart *lp = P.lotp + (size_t)g * P.lot_nb;
         if (tid == 0) {
             LotPart r; r.ab = ba; r.bv = bv; r.ma = ma; r.il = bi; r.pad = 0;
-            if (bi != INT_MAX) { r.i = lot[4 * bi]; r.j = lot[4 * bi + 1]; r.k = lot[4 * bi + 2]; r.q = lot[4 * bi + 3]; } else { r.i = r.j = r.k = r.q = 0; }
+            if (bi != INT_MAX) { r.i = lot[4 * bi]; r.j = lot[4 * bi + 1]; r.k = lot[4 * bi + 2]; r.q = lot[4 * bi + 3]; } else if (il_first < nlot) { r.i = lot[4 * il_first]; r.j = lot[4 * il_first + 1]; r.k = lot[4 * il_first + 2]; r.q = lot[4 * il_first + 3]; }   // no comparable candidate: the block's first one
+            else { r.i = r.j = r.k = r.q = 1; }
             lp[blk] = r;
             __threadfence();
             s_last = (atomicAdd(&P.lot_ctr[g], 1u) == (unsigned)(nbl - 1));
@@ -1149,6 +1152,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
                 ma = fmax(ma, r.ma);
                 if (r.ab > ba || (r.ab == ba && r.il < bi)) { ba = r.ab; bv = r.bv; bi = r.il; wi = r.i; wj = r.j; wk = r.k; wq = r.q; }
             }
+            if (bi == INT_MAX) { const LotPart r0 = lp[0]; wi = r0.i; wj = r0.j; wk = r0.k; wq = r0.q; }   // every residual a NaN: the first candidate, as idamax
             gs.amax = fmax(gs.amax, ma);                         // :467
             gs.neval += nlot;                                    // :465
             gs.rngpos += 2ull * nlot;
@@ -1162,6 +1166,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         gs.amax = fmax(gs.amax, ma);                             // :467
         gs.neval += nlot;                                        // :465
         gs.rngpos += 2ull * nlot;
+        if (bi == INT_MAX) bi = 0;                               // every residual a NaN: the first candidate, as idamax
         st.ii = lot[4 * bi]; st.jj = lot[4 * bi + 1]; st.kk = lot[4 * bi + 2]; st.qq = lot[4 * bi + 3];   // :479-484
         st.pivot = bv;
         gs.S[0] = st;
