@@ -113,6 +113,7 @@ struct DevProb {
     double *redsend, *redrecv;     // [4] this GPU's entry / the job-wide result
     double *qsend, *qall;          // [nprocs*RM*RM + 2*nprocs] partial matrices + dims of ALL groups (SUM all-reduce)
     double *qwork;                 // [(nprocs+2)*RM*RM] scratch of the quadrature tree
+    double *qscr;                  // [G][2*RM*RM] chain matrices of k_quad_chain when they do not fit the LDS (maxrank >= 98); else nullptr
     double *sumsend, *sumrecv;     // per-sweep job summary (SUM all-reduce): see SUM_* offsets
     int g0;                        // global index of local group 0
     Partial *pfull;                // [G][NM*RM*nfb] partial arg-max records of the full-superblock search (piv = -1)

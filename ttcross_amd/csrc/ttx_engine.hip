@@ -436,6 +436,8 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     h->QB = (size_t)nproc * RM * RM + 2 * nproc;
     h->SB = SUM_HDR + nproc + 5 * (size_t)(d + 1);
     A_(dev_alloc(h, &P.qsend, h->QB)); A_(dev_alloc(h, &P.qwork, ((size_t)nproc + 2) * RM * RM)); A_(dev_alloc(h, &P.sumsend, h->SB));
+    P.qscr = nullptr;
+    if (2 * sizeof(double) * ((size_t)RM * RM + 2) > 150 * 1024) A_(dev_alloc(h, &P.qscr, (size_t)G * 2 * RM * RM));
     if (W > 1) { A_(dev_alloc(h, &P.redrecv, 4)); A_(dev_alloc(h, &P.qall, h->QB)); A_(dev_alloc(h, &P.sumrecv, h->SB)); }
     else { P.redrecv = P.redsend; P.qall = P.qsend; P.sumrecv = P.sumsend; }     // one GPU: results alias the inputs
     {   // message routing: neighbour on this GPU -> its send buffer; on another GPU -> the receive buffer
@@ -983,7 +985,7 @@ static int launch_quad(ttx_engine *h, int mode, const double *w)
     DevProb &P = h->P;
     const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
     hipLaunchKernelGGL(k_quad_build, dim3(h->NC, h->G), dim3(256), lds_q, h->stream, P, mode, w);
-    hipLaunchKernelGGL(k_quad_chain, dim3(h->G), dim3(256), 2 * lds_q, h->stream, P);
+    hipLaunchKernelGGL(k_quad_chain, dim3(h->G), dim3(256), P.qscr ? 0 : 2 * lds_q, h->stream, P);
     if (h->cfg.nproc > 1) {
         int rc = allreduce_dev(h, P.qsend, P.qall, h->QB, 0);
         if (rc) return rc;
@@ -1225,7 +1227,7 @@ static int run_impl(ttx_engine *h)
             KScope ks(h, TTX_K_QUAD, nproc > 1 ? 3 : 2);
             const size_t lds_q = sizeof(double) * ((size_t)h->RM * h->RM + 2);
             hipLaunchKernelGGL(k_quad_build, dim3(h->NC, G), dim3(256), lds_q, sq, pipe ? Pq : P, 0, P.quadw);
-            hipLaunchKernelGGL(k_quad_chain, dim3(G), dim3(256), 2 * lds_q, sq, pipe ? Pq : P);
+            hipLaunchKernelGGL(k_quad_chain, dim3(G), dim3(256), P.qscr ? 0 : 2 * lds_q, sq, pipe ? Pq : P);
             if (nproc > 1) {
                 if (int rc_ = allreduce_dev(h, P.qsend, P.qall, h->QB, 0)) return rc_;     // W > 1: sq is the main stream
                 hipLaunchKernelGGL(k_quad_tree, dim3(1), dim3(256), 0, sq, pipe ? Pq : P);

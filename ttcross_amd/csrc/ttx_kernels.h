@@ -1531,7 +1531,8 @@ __global__ __launch_bounds__(256) void k_quad_chain(DevProb P)
     const int lastc = lastgroup ? P.d : gs.last;
     const int *r = P.r + (size_t)g * (P.d + 2);
     const int mym = r[first - 1];
-    double *prev = sh, *next = sh + RM * RM;
+    // the two chain matrices: LDS, or the group's global scratch when 2 RM^2 doubles exceed it (same block: barriers order the accesses)
+    double *prev = P.qscr ? P.qscr + (size_t)g * 2 * RM * RM : sh, *next = prev + RM * RM;
     const double *T0 = P.Tq + ((size_t)g * P.NC) * (size_t)RM * RM;
     for (int x = tid; x < mym * r[first]; x += blockDim.x) prev[(x % mym) + RM * (x / mym)] = T0[(x % mym) + RM * (x / mym)];
     __syncthreads();
