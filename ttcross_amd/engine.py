@@ -375,6 +375,9 @@ class TTCross:
     def quad(self, w=None):
         """dtt_quad(arg, quad) (lib/dmrgg.f90:1261); w = list of per-mode weight vectors or None."""
         v = c_double()
+        if w is not None:     # the C entry point takes the concatenated vectors on trust (as the reference takes its rank-1 train)
+            if len(w) != self.d or any(np.size(q) != int(nk) for q, nk in zip(w, self._n)):
+                raise ValueError(f"quad: {self.d} weight vectors of lengths {list(map(int, self._n))} expected")
         wa = None if w is None else np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.float64).ravel() for q in w]))
         _check(load_library().ttx_quad(self._h, _dp(wa), ctypes.byref(v)))
         return v.value
@@ -401,12 +404,16 @@ class TTCross:
     def zquad(self, w):
         """ztt_quad (lib/dmrgg.f90:1418) batched: w complex array (nf, sum(n)) of rank-1 weights; returns nf complex values."""
         ww = np.ascontiguousarray(np.atleast_2d(np.asarray(w, dtype=np.complex128)))
+        if ww.shape[1] != int(self._n.sum()):
+            raise ValueError(f"zquad: weight rows of length sum(n) = {int(self._n.sum())} expected (got {ww.shape[1]})")
         out = np.zeros(2 * ww.shape[0])
         _check(load_library().ttx_zquad(self._h, ww.shape[0], _dp(ww.view(np.float64)), _dp(out)))
         return out.view(np.complex128).copy()
 
     def tijk(self, ind):
         a = np.ascontiguousarray(ind, dtype=np.int32)
+        if a.size != self.d:
+            raise ValueError(f"tijk: a multi-index of {self.d} entries expected")
         v = c_double()
         _check(load_library().ttx_ijk(self._h, _ip(a), ctypes.byref(v)))
         return v.value
