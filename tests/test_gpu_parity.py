@@ -523,6 +523,24 @@ def test_both_sweep_paths_bit_exact(monkeypatch, fused, kind, m, n, r, piv, npro
     assert tt.quad(s["quad"]) == oo["value"]
 
 
+@pytest.mark.parametrize("kind,m,n,r,piv,own", [("c", 13, 17, 10, 2, [1, 3, 4, 9, 12]), ("d", 9, 9, 6, 3, [1, 2, 8]), ("c", 20, 9, 8, 1, [1, 18, 19])])
+def test_user_supplied_bond_groups_bit_exact(kind, m, n, r, piv, own):
+    """`mybonds` given by the caller (lib/dmrgg.f90:126-130 takes it instead of share()): uneven groups incl. one-bond groups."""
+    s = D.ising_setup(kind, m, n)
+    ng = len(own) - 1
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng, mybonds=own).run()
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng, mybonds=own)
+    _assert_identical(tt, oo)
+    assert tt.quad(s["quad"]) == oo["value"]
+
+
+@pytest.mark.parametrize("own", [[0, 3, 5], [1, 3, 6], [2, 3, 5], [1, 3, 3, 5], [1, 4, 3, 5]])
+def test_bad_bond_groups_are_refused(own):
+    s = D.ising_setup("c", 6, 9)            # d = 5: bonds 1..4, own must run from 1 to 5
+    with pytest.raises(E.TTXError, match="mybonds"):
+        E.TTCross(s["n"], s["fun_id"], s["par"], 4, pivoting=2, accuracy=s["acc"], quad=s["quad"], nproc=len(own) - 1, mybonds=own)
+
+
 @pytest.mark.parametrize("env", [{"TTX_DE_FASTDIV": "0"}, {"TTX_LOTTERY_ROWS": "2"}, {"TTX_LOTTERY_WAVE": "0"}, {"TTX_DE_V5": "1"}, {"TTX_DE_V2": "0"}],
                          ids=["general_division", "lottery_rows_with_tables", "lottery_lane_per_candidate", "relay_halfstep", "lane_per_element"])
 def test_ising_de_kernel_variants_bit_exact(env, monkeypatch):

@@ -332,6 +332,9 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     if (cfg->mybonds) h->own.assign(cfg->mybonds, cfg->mybonds + nproc + 1);
     else share(1, d - 1, nproc, h->own);                               // lib/dmrgg.f90:126-130
     for (int g = 0; g < nproc; g++) if (h->own[g + 1] <= h->own[g]) { delete h; return fail(TTX_EINVAL, "mybonds: empty group %d", g); }
+    // the groups must tile the bonds 1 .. d-1 (own(0) = 1, own(nproc) = d, lib/default.f90:78-97): anything else would address
+    // cores that do not exist or leave bonds without an owner
+    if (h->own[0] != 1 || h->own[nproc] != d) { const int a = h->own[0], b = h->own[nproc]; delete h; return fail(TTX_EINVAL, "mybonds: must run from 1 to d = %d (got %d .. %d)", d, a, b); }
     // bond groups are dealt contiguously to the GPUs of the job
     h->g0 = (int)((long long)nproc * h->wrank / W);
     h->G = (int)((long long)nproc * (h->wrank + 1) / W) - h->g0;
