@@ -534,6 +534,12 @@ def test_user_supplied_bond_groups_bit_exact(kind, m, n, r, piv, own):
     assert tt.quad(s["quad"]) == oo["value"]
 
 
+def test_mode_larger_than_the_first_is_refused_for_builtin_integrands():
+    s = _ising_problem([9, 9, 11, 9])
+    with pytest.raises(E.TTXError, match="more than the first mode"):
+        E.TTCross(s["n"], s["fun_id"], s["par"], 4, pivoting=2, accuracy=s["acc"], quad=s["quad"])
+
+
 @pytest.mark.parametrize("own", [[0, 3, 5], [1, 3, 6], [2, 3, 5], [1, 3, 3, 5], [1, 4, 3, 5]])
 def test_bad_bond_groups_are_refused(own):
     s = D.ising_setup("c", 6, 9)            # d = 5: bonds 1..4, own must run from 1 to 5

@@ -303,6 +303,11 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     if (cfg->npar < 0 || (cfg->npar > 0 && !cfg->par)) return fail(TTX_EINVAL, "ttx_create: par missing");
     if (cfg->fun_id == TTX_FUN_ISING && (cfg->npar < 2 * cfg->n[0] + 1)) return fail(TTX_EINVAL, "ttx_create: the Ising integrand needs par(1:2n+1) (nodes, weights, id)");
     if ((cfg->fun_id == TTX_FUN_STDNORM || cfg->fun_id == TTX_FUN_MVN) && cfg->npar < cfg->n[0]) return fail(TTX_EINVAL, "ttx_create: the integrand needs the nodes par(1:n)");
+    // the built-in integrands address par(ind) (and the Ising weights par(n(1) + ind)): no mode may be larger than the first
+    // (test_crs_ising.f90:181-183); with the reference this is the caller's business, here it would be a read outside the parameter vector
+    if (cfg->fun_id != TTX_FUN_HOST && cfg->fun_id != 0)
+        for (int k = 1; k < cfg->d; k++)
+            if (cfg->n[k] > cfg->n[0]) return fail(TTX_EINVAL, "ttx_create: mode %d has %d points, more than the first mode (%d): the built-in integrands index par by n(1)", k + 1, cfg->n[k], cfg->n[0]);
     if (cfg->fun_id == TTX_FUN_HOST && cfg->pivoting < 0) return fail(TTX_EINVAL, "ttx_create: pivoting = -1 is not available with a host integrand");
     if (cfg->fun_id == TTX_FUN_HOST && cfg->d > 2048) return fail(TTX_EINVAL, "ttx_create: host integrand: at most 2048 dimensions (tt_size)");
     const int W = cfg->world_size < 1 ? 1 : cfg->world_size;
