@@ -36,7 +36,11 @@ def _random_case(rng):
     r = int(rng.integers(2, 40 if kind == "c" else 9 if long_de else 14))
     piv = int(rng.choice([-1, 0, 1, 2, 3, 4])) if r * n <= 160 else int(rng.choice([0, 1, 2, 3]))
     ng = int(rng.integers(1, min(5, d - 1) + 1)) if d > 2 else 1
-    return kind, m, n, r, piv, ng
+    own = None
+    if ng > 1 and rng.random() < 0.3:        # caller-supplied uneven bond groups instead of share()
+        cuts = sorted(rng.choice(np.arange(2, d), size=ng - 1, replace=False).tolist())
+        own = [1] + [int(c) for c in cuts] + [d]
+    return kind, m, n, r, piv, ng, own
 
 
 def _setup(kind, m, n):
@@ -48,10 +52,10 @@ def _setup(kind, m, n):
     return s
 
 
-def _compare(kind, m, n, r, piv, ng):
+def _compare(kind, m, n, r, piv, ng, own=None):
     s = _setup(kind, m, n)
-    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=ng).run()
-    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=ng)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=ng, mybonds=own).run()
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=ng, mybonds=own)
     ok = (np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d]) and
           [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]] and
           [a["neval"] for a in tt.sweeps()] == [b["neval"] for b in oo["sweeps"]] and
