@@ -40,7 +40,13 @@ def _random_case(rng):
     if ng > 1 and rng.random() < 0.3:        # caller-supplied uneven bond groups instead of share()
         cuts = sorted(rng.choice(np.arange(2, d), size=ng - 1, replace=False).tolist())
         own = [1] + [int(c) for c in cuts] + [d]
-    return kind, m, n, r, piv, ng, own
+    acc = None
+    if rng.random() < 0.25:                  # the stopping rule at other thresholds (-1: no accuracy rule, maxrank sweeps)
+        acc = float(rng.choice([-1.0, 1e-3, 1e-6, 1e-10]))
+    ragged = None
+    if kind in ("c", "d", "e") and rng.random() < 0.2:      # ragged mode sizes, the first the largest
+        ragged = [n] + [int(rng.integers(1, n + 1)) for _ in range(d - 1)]
+    return kind, m, n, r, piv, ng, own, acc, ragged
 
 
 def _setup(kind, m, n):
@@ -52,8 +58,22 @@ def _setup(kind, m, n):
     return s
 
 
-def _compare(kind, m, n, r, piv, ng, own=None):
-    s = _setup(kind, m, n)
+def _ragged_ising(kind, n_list):
+    """Ising-type problem with ragged mode sizes (n(1) the largest: the integrand addresses the weights at par(n(1)+ind))."""
+    nmax = n_list[0]
+    x, w = D.lgwt(nmax)
+    par = np.zeros(2 * nmax + 1)
+    par[:nmax] = (x + 1.0) / 2
+    par[nmax:2 * nmax] = 0.5 * w * float(max(nmax // 2, 1))
+    par[2 * nmax] = {"c": 1.0, "d": 2.0, "e": 3.0}[kind]
+    quad = [np.full(nk, 1.0 / float(max(nmax // 2, 1))) for nk in n_list]
+    return dict(n=list(n_list), par=par, quad=quad, fun_id=E.TTX_FUN_ISING, aux=None, acc=500 * D.EPS, tru=None)
+
+
+def _compare(kind, m, n, r, piv, ng, own=None, acc=None, ragged=None):
+    s = _ragged_ising(kind, ragged) if ragged else _setup(kind, m, n)
+    if acc is not None:
+        s["acc"] = acc
     tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=ng, mybonds=own).run()
     oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"], nproc=ng, mybonds=own)
     ok = (np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d]) and
