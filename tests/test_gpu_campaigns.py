@@ -167,3 +167,42 @@ def test_fuzz_multi_process_jobs():
         for p in procs:
             o, e = p.communicate(timeout=600)
             assert p.returncode == 0 and " OK" in o, f"world={world} {kind} {m} {n} {r} {piv} groups={ng}\n" + o[-1500:] + e[-1500:]
+
+
+def test_fuzz_reference_driver_on_the_engine_vs_genuine_reference():
+    """Random command lines for the reference's OWN test_crs_ising.f90: compiled unchanged against the drop-in modules and run on the
+    GPU (oracle/_ref/dropin_test_crs_ising) against the GENUINE reference run on the host at the same moment
+    (oracle/_ref/test_crs_ising, test infrastructure; both binaries are built in the build container and travel).  The genuine
+    reference sums with MKL, so a near-tie may turn a later pivot: the first three sweeps must agree in (erank, n_evals) and to
+    2e-13 in the value; the number of cases that agree in EVERY sweep is reported."""
+    from golden_util import parse_log
+    ref = os.path.join(ROOT, "oracle", "_ref", "test_crs_ising")
+    drop = os.path.join(ROOT, "oracle", "_ref", "dropin_test_crs_ising")
+    if not (os.path.exists(ref) and os.path.exists(drop)):
+        pytest.skip("oracle/_ref binaries not built (needs /root/reference + amdflang: make -C oracle ref dropin)")
+    ncases = int(os.environ.get("TTX_REFFUZZ_CASES", "3"))
+    rng = np.random.default_rng(int(os.environ.get("TTX_FUZZ_SEED", "20261004")) + 3)
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="4")
+    full, bad = 0, []
+    for _ in range(ncases):
+        kind = str(rng.choice(["C", "C", "D", "E"]))
+        m = int(rng.integers(3, 15 if kind == "C" else 10)); n = int(rng.choice([9, 17, 25, 33])); r = int(rng.integers(3, 17)); piv = int(rng.integers(0, 4))
+        argv = [kind, str(m), str(n), str(r), str(piv)]
+        a = subprocess.run([ref] + argv, capture_output=True, text=True, env=env, timeout=600)
+        b = subprocess.run([drop] + argv, capture_output=True, text=True, env=env, timeout=600)
+        if a.returncode != 0 or b.returncode != 0:
+            bad.append((argv, "exit codes", a.returncode, b.returncode)); continue
+        ra, va, na = parse_log(a.stdout)
+        rb, vb, nb = parse_log(b.stdout)
+        k = 0
+        for x, y in zip(ra, rb):
+            if x["erank"] == y["erank"] and x["neval"] == y["neval"] and abs(x["val"] - y["val"]) <= 2e-13 * abs(x["val"]):
+                k += 1
+            else:
+                break
+        if k == len(ra) == len(rb) and na == nb:
+            full += 1
+        if k < min(3, len(ra)):
+            bad.append((argv, f"only {k} leading sweeps agree of {len(ra)} / {len(rb)}"))
+    print(f"reference-driver fuzz: {full} of {ncases} command lines agree in every sweep")
+    assert not bad, f"command lines on which the drop-in departs from the genuine reference early: {bad}"
