@@ -170,28 +170,34 @@ def test_fuzz_multi_process_jobs():
 
 
 def test_fuzz_reference_driver_on_the_engine_vs_genuine_reference():
-    """Random command lines for the reference's OWN test_crs_ising.f90: compiled unchanged against the drop-in modules and run on the
-    GPU (oracle/_ref/dropin_test_crs_ising) against the GENUINE reference run on the host at the same moment
-    (oracle/_ref/test_crs_ising, test infrastructure; both binaries are built in the build container and travel).  The genuine
-    reference sums with MKL, so a near-tie may turn a later pivot: the first three sweeps must agree in (erank, n_evals) and to
-    2e-13 in the value; the number of cases that agree in EVERY sweep is reported."""
+    """Random command lines for the reference's OWN test_crs_{ising,stdnorm,mvn}.f90: compiled unchanged against the drop-in modules
+    and run on the GPU (oracle/_ref/dropin_test_crs_*) against the GENUINE reference run on the host at the same moment
+    (oracle/_ref/test_crs_*, test infrastructure; the binaries are built in the build container and travel).  The genuine
+    reference sums with MKL (and inverts the mvn covariance with LAPACK), so a near-tie may turn a later pivot: the first three
+    sweeps (stdnorm: two, mvn: the first) must agree in (erank, n_evals) and to 2e-13 in the value; the number of cases that agree in EVERY sweep
+    is reported."""
     from golden_util import parse_log
-    ref = os.path.join(ROOT, "oracle", "_ref", "test_crs_ising")
-    drop = os.path.join(ROOT, "oracle", "_ref", "dropin_test_crs_ising")
-    if not (os.path.exists(ref) and os.path.exists(drop)):
+    exe = lambda pre, drv: os.path.join(ROOT, "oracle", "_ref", f"{pre}test_crs_{drv}")
+    if not all(os.path.exists(exe(pre, drv)) for pre in ("", "dropin_") for drv in ("ising", "stdnorm", "mvn")):
         pytest.skip("oracle/_ref binaries not built (needs /root/reference + amdflang: make -C oracle ref dropin)")
     ncases = int(os.environ.get("TTX_REFFUZZ_CASES", "3"))
     rng = np.random.default_rng(int(os.environ.get("TTX_FUZZ_SEED", "20261004")) + 3)
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="4")
     full, bad = 0, []
     for _ in range(ncases):
-        kind = str(rng.choice(["C", "C", "D", "E"]))
-        m = int(rng.integers(3, 15 if kind == "C" else 10)); n = int(rng.choice([9, 17, 25, 33])); r = int(rng.integers(3, 17)); piv = int(rng.integers(0, 4))
-        argv = [kind, str(m), str(n), str(r), str(piv)]
-        a = subprocess.run([ref] + argv, capture_output=True, text=True, env=env, timeout=600)
-        b = subprocess.run([drop] + argv, capture_output=True, text=True, env=env, timeout=600)
+        drv = str(rng.choice(["ising", "ising", "ising", "stdnorm", "mvn"]))
+        n = int(rng.choice([9, 17, 25, 33])); r = int(rng.integers(3, 17)); piv = int(rng.integers(0, 4))
+        if drv == "ising":
+            kind = str(rng.choice(["C", "C", "D", "E"]))
+            argv = [kind, str(int(rng.integers(3, 15 if kind == "C" else 10))), str(n), str(r), str(piv)]
+        else:                                   # the exp-based integrands: the leading sweeps only (the noise floor decides near-ties)
+            argv = [str(int(rng.integers(2, 9))), str(n), str(r), str(piv)]
+        need = {"ising": 3, "stdnorm": 2, "mvn": 1}[drv]      # mvn: equal correlations make exact ties, settled by the last bits of the inverse covariance
+        argv_t = [drv] + argv
+        a = subprocess.run([exe("", drv)] + argv, capture_output=True, text=True, env=env, timeout=600)
+        b = subprocess.run([exe("dropin_", drv)] + argv, capture_output=True, text=True, env=env, timeout=600)
         if a.returncode != 0 or b.returncode != 0:
-            bad.append((argv, "exit codes", a.returncode, b.returncode)); continue
+            bad.append((argv_t, "exit codes", a.returncode, b.returncode)); continue
         ra, va, na = parse_log(a.stdout)
         rb, vb, nb = parse_log(b.stdout)
         k = 0
@@ -202,7 +208,7 @@ def test_fuzz_reference_driver_on_the_engine_vs_genuine_reference():
                 break
         if k == len(ra) == len(rb) and na == nb:
             full += 1
-        if k < min(3, len(ra)):
-            bad.append((argv, f"only {k} leading sweeps agree of {len(ra)} / {len(rb)}"))
+        if k < min(need, len(ra)):
+            bad.append((argv_t, f"only {k} leading sweeps agree of {len(ra)} / {len(rb)}"))
     print(f"reference-driver fuzz: {full} of {ncases} command lines agree in every sweep")
     assert not bad, f"command lines on which the drop-in departs from the genuine reference early: {bad}"
