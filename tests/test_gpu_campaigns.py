@@ -192,10 +192,20 @@ def test_fuzz_reference_driver_on_the_engine_vs_genuine_reference():
             argv = [kind, str(int(rng.integers(3, 15 if kind == "C" else 10))), str(n), str(r), str(piv)]
         else:                                   # the exp-based integrands: the leading sweeps only (the noise floor decides near-ties)
             argv = [str(int(rng.integers(2, 9))), str(n), str(r), str(piv)]
+        # Ising also as P bond groups: the reference under `mpiexec -np P` (the build with the right-going exchange re-inserted,
+        # oracle/_ref/test_crs_ising_mpi) beside the drop-in with TTX_NGROUPS=P on one GPU
+        groups = 1
+        mpi_exe, mpiexec = exe("", "ising") + "_mpi", "/opt/conda/bin/mpiexec"
+        if drv == "ising" and os.path.exists(mpi_exe) and os.path.exists(mpiexec) and rng.random() < 0.4:
+            groups = int(rng.integers(2, min(5, int(argv[1]) - 2) + 1)) if int(argv[1]) - 2 >= 2 else 1
         need = {"ising": 3, "stdnorm": 2, "mvn": 1}[drv]      # mvn: equal correlations make exact ties, settled by the last bits of the inverse covariance
-        argv_t = [drv] + argv
-        a = subprocess.run([exe("", drv)] + argv, capture_output=True, text=True, env=env, timeout=600)
-        b = subprocess.run([exe("dropin_", drv)] + argv, capture_output=True, text=True, env=env, timeout=600)
+        argv_t = [drv] + argv + ([f"groups={groups}"] if groups > 1 else [])
+        if groups > 1:
+            a = subprocess.run([mpiexec, "-np", str(groups), mpi_exe] + argv, capture_output=True, text=True, env=dict(env, OMP_NUM_THREADS="1"), timeout=600)
+            b = subprocess.run([exe("dropin_", drv)] + argv, capture_output=True, text=True, env=dict(env, TTX_NGROUPS=str(groups)), timeout=600)
+        else:
+            a = subprocess.run([exe("", drv)] + argv, capture_output=True, text=True, env=env, timeout=600)
+            b = subprocess.run([exe("dropin_", drv)] + argv, capture_output=True, text=True, env=env, timeout=600)
         if a.returncode != 0 or b.returncode != 0:
             bad.append((argv_t, "exit codes", a.returncode, b.returncode)); continue
         ra, va, na = parse_log(a.stdout)
