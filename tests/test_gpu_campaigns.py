@@ -283,3 +283,54 @@ def test_fuzz_tt_lib_vs_genuine_reference():
     print(f"tt_lib fuzz: {ncases - diverged} of {ncases} trains compared ({diverged} crosses took another pivot path than the reference's)")
     assert not bad, f"cases (m, n, r, piv) that depart from the genuine reference's tt_lib: {bad}"
     assert diverged <= max(1, ncases // 5)
+
+
+def test_fuzz_accchk_and_zquad_vs_genuine_reference():
+    """dtt_accchk and ztt_quad against the GENUINE reference run live (oracle/_ref/ref_accchk, ref_zquad) on random Ising-C jobs.
+    accchk draws its samples from the same random stream as the reference, so the worst sample and the sup norms must be THE
+    SAME numbers (the value norms exactly; the error norms to 1e-6: the reference evaluates the train with MKL), provided the
+    cross took the same pivots -- the cases where it did not are counted (see the reference-driver fuzz)."""
+    exa, exz = (os.path.join(ROOT, "oracle", "_ref", x) for x in ("ref_accchk", "ref_zquad"))
+    if not (os.path.exists(exa) and os.path.exists(exz)):
+        pytest.skip("oracle/_ref/ref_accchk / ref_zquad not built (needs /root/reference + amdflang: make -C oracle ref)")
+    ncases = int(os.environ.get("TTX_ACCFUZZ_CASES", "2"))
+    rng = np.random.default_rng(int(os.environ.get("TTX_FUZZ_SEED", "20261004")) + 5)
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="4")
+    bad, diverged = [], 0
+    for _ in range(ncases):
+        m = int(rng.integers(4, 12)); n = int(rng.choice([9, 17, 25, 33])); r = int(rng.integers(3, 20)); piv = int(rng.integers(0, 4)); nlot = int(rng.integers(50, 4000))
+        s = D.ising_setup("c", m, n)
+        why = []
+        # ---- accchk (the fixture driver passes the quadrature weights to dtt_dmrgg) ----
+        p = subprocess.run([exa, str(m), str(n), str(r), str(piv), str(nlot)], capture_output=True, text=True, env=env, timeout=600)
+        ref = [float(x) for l in p.stdout.splitlines() if l.startswith("accchk") for x in l.split()[1:]]
+        refpiv = [int(x) for l in p.stdout.splitlines() if l.startswith("pivot") for x in l.split()[1:]]
+        tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"]).run()
+        g = tt.accchk(nlot)
+        tt.close()
+        if g["ainf"] != ref[2]:
+            diverged += 1                       # another sample set would not give the identical sup norm: the crosses differ
+        else:
+            # the worst sample is a statement about the interpolation error only where that error is above the rounding noise
+            # (a train that reproduces a small tensor exactly has its "worst" sample wherever the last bits fall)
+            if (ref[0] > 1e-9 * ref[2] and list(g["pivot"]) != refpiv) or abs(g["afro"] - ref[3]) > 1e-13 * ref[3]:
+                why.append("accchk values")
+            if abs(g["einf"] - ref[0]) > 1e-5 * ref[0] + 1e-13 * ref[2] or abs(g["efro"] - ref[1]) > 1e-5 * ref[1] + 1e-13 * ref[3]:
+                why.append("accchk errors")
+        # ---- zquad (no quadrature in dtt_dmrgg, as the fork's driver) ----
+        p = subprocess.run([exz, str(m), str(n), str(r), str(piv)], capture_output=True, text=True, env=env, timeout=600)
+        refz = [l.split() for l in p.stdout.splitlines() if l.startswith("zquad")]
+        tz = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"]).run()
+        sc = float(n // 2); x = s["par"][:n]
+        W = np.array([np.tile((1.0 / sc) * np.exp(1j * (k * np.pi / 300.0) * np.exp(x) / (m - 1)), m - 1) for k in range(len(refz))])
+        got = tz.zquad(W)
+        tz.close()
+        for k in range(len(refz)):
+            want = complex(float(refz[k][2]), float(refz[k][3]))
+            if abs(got[k] - want) > 1e-9 * abs(want):
+                why.append(f"zquad {k}"); break
+        if why:
+            bad.append(((m, n, r, piv, nlot), why))
+    print(f"accchk / zquad fuzz: {ncases} jobs, {diverged} with another pivot path than the reference's")
+    assert not bad, f"cases (m, n, r, piv, nlot) that depart from the genuine reference: {bad}"
+    assert diverged <= max(1, ncases // 5)
