@@ -41,6 +41,30 @@ __global__ __launch_bounds__(64) void k_dpp_chain(const double *g, int nbatch, i
     if (lane == 0 && blockIdx.x == 0) out[0] = 10.0 * (double)(t1 - t0) / ((double)reps * nbatch * 16);
     if (blockIdx.x == 0) chk[lane] = a;
 }
+// (1b) the U-wave pattern of k_halfstep_det: the chain value after every factor is also stored to LDS (one 512-byte row per factor)
+template <int STORE>
+__global__ __launch_bounds__(64) void k_dpp_store(const double *g, int nbatch, int reps, double *out, double *chk)
+{
+    __shared__ double buf[48 * 64];
+    const int lane = threadIdx.x;
+    double a = 1.0;
+    long long t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) {
+        const double *p = g + (lane & 15);
+        double f = p[0];
+        for (int b = 0; b < nbatch; b++) {
+            const double fn = p[16 * (b + 1)];
+            double *o = buf + (size_t)(b % 3) * 16 * 64 + lane;
+#define ST(k) a = a * bc<k>(f); if (STORE) o[k * 64] = a;
+            ST(0) ST(1) ST(2) ST(3) ST(4) ST(5) ST(6) ST(7) ST(8) ST(9) ST(10) ST(11) ST(12) ST(13) ST(14) ST(15)
+#undef ST
+            f = fn;
+        }
+    }
+    long long t1 = wall_clock64();
+    if (lane == 0 && blockIdx.x == 0) out[0] = 10.0 * (double)(t1 - t0) / ((double)reps * nbatch * 16);
+    if (blockIdx.x == 0) chk[lane] = a + buf[lane];
+}
 // reference for (1): the same product as a plain sequential loop on one lane
 __global__ void k_seq_chain(const double *g, int n, double *o) { double a = 1.0; for (int i = 0; i < n; i++) a = a * g[i]; *o = a; }
 
@@ -218,6 +242,16 @@ int main()
         hipLaunchKernelGGL(k_dpp_chain, dim3(blocks), dim3(64), 0, 0, g, NB, 20, out, chk);
         CK(hipMemcpy(o, out, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(c, chk, 512, hipMemcpyDeviceToHost));
         printf("dpp chain, %4d blocks of one wave: %.2f ns per factor\n", blocks, o[0]);
+    }
+    {
+        hipLaunchKernelGGL(k_dpp_store<0>, dim3(1), dim3(64), 0, 0, g, NB, 20, out, chk);
+        hipLaunchKernelGGL(k_dpp_store<0>, dim3(1), dim3(64), 0, 0, g, NB, 20, out, chk);
+        CK(hipMemcpy(o, out, 8, hipMemcpyDeviceToHost));
+        printf("dpp chain, one register of 16 factors at a time, no store: %.2f ns per factor\n", o[0]);
+        hipLaunchKernelGGL(k_dpp_store<1>, dim3(1), dim3(64), 0, 0, g, NB, 20, out, chk);
+        hipLaunchKernelGGL(k_dpp_store<1>, dim3(1), dim3(64), 0, 0, g, NB, 20, out, chk);
+        CK(hipMemcpy(o, out, 8, hipMemcpyDeviceToHost));
+        printf("the same with the running product stored to LDS after every factor: %.2f ns per factor\n", o[0]);
     }
     // exactness: 20 repetitions of the N-factor product on lane 0 vs the plain loop
     {

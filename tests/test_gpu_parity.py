@@ -547,13 +547,16 @@ def test_bad_bond_groups_are_refused(own):
         E.TTCross(s["n"], s["fun_id"], s["par"], 4, pivoting=2, accuracy=s["acc"], quad=s["quad"], nproc=len(own) - 1, mybonds=own)
 
 
-@pytest.mark.parametrize("env", [{"TTX_DE_FASTDIV": "0"}, {"TTX_LOTTERY_ROWS": "2"}, {"TTX_LOTTERY_WAVE": "0"}, {"TTX_DE_V5": "1"}, {"TTX_DE_V2": "0"}],
-                         ids=["general_division", "lottery_rows_with_tables", "lottery_lane_per_candidate", "relay_halfstep", "lane_per_element"])
+@pytest.mark.parametrize("env", [{"TTX_DE_FASTDIV": "0"}, {"TTX_LOTTERY_ROWS": "2"}, {"TTX_LOTTERY_WAVE": "0"}, {"TTX_DE_V5": "1"}, {"TTX_DE_V2": "0"},
+                                 {"TTX_DE_TEAM": "0"}, {"TTX_DE_TEAM_UNITS": "1000000"}, {"TTX_DE_TEAM_UNITS": "1000000", "TTX_DE_FASTDIV": "0"}],
+                         ids=["general_division", "lottery_rows_with_tables", "lottery_lane_per_candidate", "relay_halfstep", "lane_per_element",
+                              "wave_per_unit_halfstep", "team_halfstep_always", "team_halfstep_general_division"])
 def test_ising_de_kernel_variants_bit_exact(env, monkeypatch):
     """Every selectable variant of the D/E kernels gives the oracle's bits: the IEEE division instead of the short sequence for
     nodes in [0,1], the row-wise lottery with the pivots' factor tables (default: without), the lottery and the boundary corners
-    with one lane per element, the four-wave relay half-step, the round-1 lane-per-element kernels.  The second case has two
-    bond groups (boundary corners)."""
+    with one lane per element, the four-wave relay half-step, the round-1 lane-per-element kernels, the half-step without the
+    16-wave teams (default: teams while the ranks are small) and with teams at every rank.  The second case has two bond groups
+    (boundary corners)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for kind, m, n, r, piv, ng in [("d", 45, 9, 6, 2, 1), ("e", 38, 5, 5, 3, 2)]:

@@ -674,3 +674,287 @@ __global__ __launch_bounds__(64) void k_lottery_eval_de_rows(DevProb P)
     const double f = de_finish_vals(P.ising_id, a, m, xv, wv);
     if (n == 0 && il_raw < nlot) P.lotf[(size_t)g * P.lot_max + il] = f;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_halfstep_det: the half-step of ONE (pivot, mode-chunk) by a TEAM of 14 waves on one CU (end of round 2).
+// k_halfstep_de keeps one wave per unit: while the ranks are small (a D_256 run spends most of its sweeps below rank 20)
+// a launch has far fewer waves than the chip has SIMDs, and each of them divides at the lone-wave rate of 34 ns per pair.
+// The divisions of a unit are independent of each other -- only the running product `a` (and, along one row of the pair
+// triangle, the running node product u) is a chain -- so the team splits the roles:
+//   wave 1      (U) walks the rows of the triangle and writes u of every bond-spanning pair (one multiply per pair; the node
+//                   values come 16 at a time in one register and are picked by DPP row broadcasts),
+//   waves 2..13 (D) turn tiles of four consecutive u into the factors ((u-1)/(u+1))^2 in place, stage by stage,
+//   wave 0      (M) multiplies the factors into `a` in the reference's order, the tabulated factors of the pivots
+//                   (TL before every row, TR at the end) in between -- DPP row broadcasts out of a register that holds 16 of
+//                   them instead of LDS broadcasts --, and then finishes the element exactly as k_halfstep_de does (b-part,
+//                   weights, store, residual, arg-max record).
+// The three roles work on three consecutive chunks of 48 slots (three blocks of 16) in three LDS buffers and meet at ONE
+// workgroup barrier per chunk: no flags, no polling, nothing that can hang.  A row of the triangle is padded to whole blocks:
+// a padding slot (and the absent first pair of the last row) carries u = 0, whose factor is exactly 1, so M multiplies every
+// slot without a test.  Per element every product, difference and quotient and their order are those of k_halfstep_de:
+// bit-identical.
+// ------------------------------------------------------------------------------------------------------------------
+#define DET_ND 12                 // dividing waves
+#define DET_NW (DET_ND + 2)
+__host__ __device__ inline int det_vs(int m) { return ((m + 7) & ~7) + 8; }
+__host__ __device__ inline size_t det_lds_doubles(int m) { return (size_t)4 * det_vs(m) + 128 + (det_vs(m) + 48) + (size_t)3 * DET_ND * 4 * 64; }
+
+#define TTX_RB8LO(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define TTX_RB8HI(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+// wave-uniform stream of doubles consumed in order by ONE wave, delivered by DPP row broadcasts: the 64 entries of a batch
+// are parked in the LDS ring and read back as four registers whose lane n (of every DPP row) holds entry 16 b + n.  A run
+// that starts or ends inside a block of 16 multiplies the positions outside it by 1.0 (exact) instead of branching per factor.
+struct WStreamD {
+    const double *g; double *buf; double rA, rB, f0, f1, f2, f3; int total, nextb, rd;
+    __device__ __forceinline__ double ld(int b, int lane) const { const int ix = b * 64 + lane; return ix < total ? g[ix] : 1.0; }
+    __device__ __forceinline__ void init(const double *g_, int total_, double *buf_, int lane)
+    { g = g_; total = total_; buf = buf_; rA = ld(0, lane); rB = ld(1, lane); nextb = 2; rd = 64; f0 = f1 = f2 = f3 = 1.0; }
+    __device__ __forceinline__ void refill(int lane)
+    {
+        __builtin_amdgcn_wave_barrier();
+        buf[lane] = rA; rA = rB; rB = ld(nextb, lane); nextb++; rd = 0;
+        __builtin_amdgcn_wave_barrier();
+        const int n = lane & 15;
+        f0 = buf[n]; f1 = buf[16 + n]; f2 = buf[32 + n]; f3 = buf[48 + n];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // one block of 16: entries off .. off+c-1 of register fb (positions outside the run are multiplied as 1.0)
+    __device__ __forceinline__ double fold(double a, double fb, int off, int c, int n) const
+    {
+        const double fm = (n >= off && n < off + c) ? fb : 1.0;
+#define TTX_RB_ALL(k) a = a * rowbc<k>(fm);
+        if (off < 8) { TTX_RB8LO(TTX_RB_ALL) }
+        if (off + c > 8) { TTX_RB8HI(TTX_RB_ALL) }
+#undef TTX_RB_ALL
+        return a;
+    }
+    __device__ __forceinline__ double chain(double a, int cnt, int lane)
+    {
+        const int n = lane & 15;
+        while (cnt > 0) {
+            if (rd == 64) refill(lane);
+            // the four registers are addressed statically (a run-time index would put them into scratch memory)
+#define TTX_DETB(b, fb) if ((rd >> 4) == b && cnt > 0) { const int off = rd & 15, c = cnt < 16 - off ? cnt : 16 - off; a = fold(a, fb, off, c, n); rd += c; cnt -= c; }
+            TTX_DETB(0, f0) TTX_DETB(1, f1) TTX_DETB(2, f2) TTX_DETB(3, f3)
+#undef TTX_DETB
+        }
+        return a;
+    }
+};
+
+#ifdef TTX_STAMPS
+#ifndef DET_STAMPG
+#define DET_STAMPG 3
+#endif
+#define DET_T0() long long st_t = wall_clock64()
+#define DET_ACC(slot) do { const long long st_n = wall_clock64(); if (st_on && lane == 0) atomicAdd((unsigned long long *)&P.gs[0].stamp[1][slot], (unsigned long long)(st_n - st_t)); st_t = st_n; } while (0)
+#else
+#define DET_T0() do {} while (0)
+#define DET_ACC(slot) do {} while (0)
+#endif
+template <bool FAST>
+__global__ __launch_bounds__(64 * DET_NW) void k_halfstep_det(DevProb P, int h, int dir, int mode)
+{
+    extern __shared__ __align__(16) double dyn[];
+    __shared__ StepState cur;
+    constexpr int ND = DET_ND, CHS = ND * 4, NBK = CHS / 16, NT_ = 64 * DET_NW;
+    // everything that steers the control flow is made wave-uniform explicitly (values read from LDS / global memory are
+    // per-lane registers to the compiler: loop counters and branches would otherwise run on the vector unit)
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = UNI(tid >> 6), m = P.d;
+    GroupState &gs = P.gs[g];
+    if (tid == 0) { cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]); }
+    __syncthreads();
+    if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
+    const bool iscol = (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
+    const int p = UNI(cur.p), r0 = UNI(cur.r0), r1 = UNI(cur.r1), r2 = UNI(cur.r2), n1 = UNI(cur.n1), n2 = UNI(cur.n2), first = UNI(gs.first);
+    const int c_ii = UNI(cur.ii), c_jj = UNI(cur.jj), c_kk = UNI(cur.kk), c_qq = UNI(cur.qq);
+    const int nf = iscol ? r0 * n1 : n2 * r2;
+    const int nv = iscol ? r0 : r2, nm = iscol ? n1 : n2, nch = (nm + 63) >> 6;
+    const int npart = nv * nch;
+    const int w = blockIdx.x;
+    const int crs = UNI(cur.crs) + 1;
+    const int havecol = UNI(cur.havecol) | (iscol ? 1 : 0), haverow = UNI(cur.haverow) | (iscol ? 0 : 1);
+    const int done = (mode == 1 || mode == 2) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
+    const bool resid = (mode == 0) && !done;
+    if (npart > (int)gridDim.x) {       // the host sized the grid from its bound on the ranks: never expected; the run is repeated without teams
+        if (w == 0 && tid == 0) { atomicAdd(&P.ctl[3], 1); P.ctl[0] = 1; }
+        return;
+    }
+    if (w == 0 && tid == 0) {
+        StepState nx = cur;
+        nx.crs = crs; nx.havecol = havecol; nx.haverow = haverow; nx.done = done;
+        nx.pending = resid ? (iscol ? 1 : 2) : 0;
+        nx.npart = npart;
+        gs.S[h + 1] = nx;
+        if (mode != 2) gs.neval += nf;                                        // :527 / :560 / :509
+        gs.bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
+        gs.n_resid += resid ? 1 : 0;
+    }
+    if (w >= npart) return;
+    const int pv = w / nch, vmode = (w - pv * nch) * 64 + lane;        // varying pivot, mode index (0-based)
+    const bool live = vmode < nm;
+    const int A = p - 1, B = m - p - 1;
+    const int pl = iscol ? pv : c_ii - 1, qr = iscol ? c_qq - 1 : pv;         // left / right pivot of this unit
+    const int n1m = UNI(P.n[1]);
+    const double *nodes = P.par, *weights = P.par + n1m;                          // 0-based here
+    // rows i = 0..A+1 of the triangle, RL slots each (slot 0: pair with dim p -- absent in row A+1 --, slot 1: with dim p+1,
+    // slot 2+j: with right dim j), padded to BPR blocks of 16 slots; chunk k = blocks [k NBK, (k+1) NBK) of the (A+2) BPR blocks
+    const int RL = B + 2, BPR = (RL + 15) >> 4, NBT = (A + 2) * BPR, NCH = (NBT + NBK - 1) / NBK;
+    // LDS: UL[VS] | xl[VS] | wl[VS] | wr[VS] | ring L | ring R | V[VS+48] (node of slot c of a row: V[2+j] = xr[j], 0 from RL on) | 3 chunks
+    const int VS = det_vs(m);
+    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *wr = wl + VS, *ringL = wr + VS, *ringR = ringL + 64, *V = ringR + 64, *xr = V + 2;
+    double *chunks = V + VS + 48;
+    const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
+    const double *TLg = P.deTL + (size_t)g * tsz + (size_t)pl * NP, *TRg = P.deTR + (size_t)g * tsz + (size_t)qr * NP;
+    const double *ULg = P.deUL + ((size_t)g * P.RM + pl) * (m + 1);
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    for (int x = tid; x < A; x += NT_) { const int ix = Lt[(size_t)x * P.RM + pl] - 1; xl[x] = nodes[ix]; wl[x] = weights[ix]; }
+    for (int x = tid; x < B; x += NT_) { const int ix = Rt[(size_t)x * P.RM + qr] - 1; xr[x] = nodes[ix]; wr[x] = weights[ix]; }
+    for (int x = RL + tid; x < 16 * BPR + 32; x += NT_) V[x] = 0.0;
+    if (tid < 2) V[tid] = 0.0;
+    for (int x = tid; x <= A + 2; x += NT_) UL[x] = (x <= A) ? ULg[x] : 1.0;
+    const int i1 = iscol ? (live ? vmode : 0) : c_jj - 1, i2 = iscol ? c_kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
+    const double x1 = nodes[i1], x2 = nodes[i2];
+    const int n16 = lane & 15;
+    WStreamD sl, sr;
+    double a = 1.0, u = 0.0, uln = 0.0;
+    int ti = 0, bc = 0;                                                // U and M: row / block-in-row of the next block to visit
+    if (wv == 0) sl.init(TLg, A * (A + 1) / 2, ringL, lane);
+    __syncthreads();
+    if (wv == 1) uln = UL[0];
+#ifdef TTX_STAMPS
+    const bool st_on = (g == DET_STAMPG % (int)gridDim.y) && w == 0;
+    if (st_on && tid == 0) atomicAdd((unsigned long long *)&P.gs[0].nstamp[1], 1ull);
+#endif
+    DET_T0();
+    for (int R = 0; R < NCH + 2; R++) {
+        if (wv == 1) {
+            if (R < NCH) {                                             // U: the running node products of chunk R
+                double *cb = chunks + (size_t)(R % 3) * CHS * 64 + lane;
+                const int nb = (NBT - R * NBK) < NBK ? (NBT - R * NBK) : NBK;
+                int lbc = bc;
+                double f = V[lbc * 16 + n16];
+                for (int kb = 0; kb < nb; kb++) {
+                    if (++lbc == BPR) lbc = 0;
+                    const double fnx = V[lbc * 16 + n16];              // the node values of the next block: one block ahead
+                    const bool head = (bc == 0), lastrow = (ti == A + 1);
+                    double *out = cb + (size_t)kb * 16 * 64;
+                    if (head) { u = uln; uln = UL[ti + 1]; }           // UL[A+1] = 1: the row that starts after dim p
+                    const double m0 = head ? (lastrow ? 1.0 : x1) : rowbc<0>(f);
+                    const double m1 = head ? x2 : rowbc<1>(f);
+                    u = u * m0; out[0] = (head && lastrow) ? 0.0 : u;
+                    u = u * m1; out[64] = u;
+#define TTX_U_STEP(k) u = u * rowbc<k>(f); out[k * 64] = u;
+                    TTX_U_STEP(2) TTX_U_STEP(3) TTX_U_STEP(4) TTX_U_STEP(5) TTX_U_STEP(6) TTX_U_STEP(7)
+                    TTX_RB8HI(TTX_U_STEP)
+#undef TTX_U_STEP
+                    f = fnx;
+                    if (++bc == BPR) { bc = 0; ti++; }
+                }
+            }
+            DET_ACC(3);
+        } else if (wv >= 2) {
+            // waves go round-robin to the four SIMDs: waves 4k and 4k+1 share theirs with M and U and take three slots of a
+            // block, waves 4k+2 and 4k+3 five (blocks of 16 slots = 3 + 3 + 5 + 5)
+            const int dv = wv - 2, bq = dv >> 2, role = wv & 3;         // role 0/1: 3 slots at 0 / 3 ; role 2/3: 5 slots at 6 / 11
+            const int blk = (R - 1) * NBK + bq;
+            if (R >= 1 && blk < NBT) {                                 // D: its slots of block bq of chunk R-1, in place
+                double *cb = chunks + ((size_t)((R - 1) % 3) * CHS + (size_t)bq * 16) * 64 + lane;
+                if (role < 2) {
+                    double *cp = cb + (size_t)(role * 3) * 64;
+                    double uu[3], t[3];
+#pragma unroll
+                    for (int s = 0; s < 3; s++) uu[s] = cp[s * 64];
+                    de_t2xw<FAST, 3>(uu, t);
+#pragma unroll
+                    for (int s = 0; s < 3; s++) cp[s * 64] = t[s];
+                } else {
+                    double *cp = cb + (size_t)(6 + (role - 2) * 5) * 64;
+                    double uu[5], t[5];
+#pragma unroll
+                    for (int s = 0; s < 5; s++) uu[s] = cp[s * 64];
+                    de_t2xw<FAST, 5>(uu, t);
+#pragma unroll
+                    for (int s = 0; s < 5; s++) cp[s * 64] = t[s];
+                }
+            }
+            if (wv == 2) DET_ACC(5);
+        } else if (R >= 2) {                                           // M: the factors of chunk R-2 into `a`, in order
+            const double *cb = chunks + (size_t)((R - 2) % 3) * CHS * 64 + lane;
+            const int nb = (NBT - (R - 2) * NBK) < NBK ? (NBT - (R - 2) * NBK) : NBK;
+            // three buffers of half a block rotate: the loads run two half-blocks (16 multiplies) ahead of the product
+            double q0[8], q1[8], q2[8];
+#define DET_LD(q, hb) _Pragma("unroll") for (int x = 0; x < 8; x++) q[x] = cb[(size_t)((hb) * 8 + x) * 64];
+#define DET_F(q) _Pragma("unroll") for (int x = 0; x < 8; x++) a = a * q[x];
+#define DET_HEAD() if (bc == 0 && ti <= A) { DET_ACC(1); a = sl.chain(a, A - ti, lane); DET_ACC(0); }
+#define DET_NEXT() if (++bc == BPR) { bc = 0; ti++; }
+            DET_LD(q0, 0) DET_LD(q1, 1)
+            DET_HEAD() DET_LD(q2, 2) DET_F(q0) DET_LD(q0, 3) DET_F(q1) DET_NEXT()
+            if (nb > 1) { DET_HEAD() DET_LD(q1, 4) DET_F(q2) DET_LD(q2, 5) DET_F(q0) DET_NEXT() }
+            if (nb > 2) { DET_HEAD() DET_F(q1) DET_F(q2) DET_NEXT() }
+#undef DET_LD
+#undef DET_F
+#undef DET_HEAD
+#undef DET_NEXT
+            DET_ACC(1);
+        }
+        __syncthreads();
+        if (wv == 0) DET_ACC(2); else if (wv == 1) DET_ACC(4); else if (wv == 2) DET_ACC(6);
+    }
+    if (wv != 0) return;
+    sr.init(TRg, B * (B + 1) / 2, ringR, lane);
+    a = sr.chain(a, B * (B + 1) / 2, lane);
+    DET_ACC(8);
+    const double w1 = weights[i1], w2 = weights[i2];
+    // ---- b-part (id 2) and the weights (:197-218), order of de_finish ----
+    const int id = P.ising_id;
+    double b = 0.0;
+    if (id == 2) {
+        double v = 1.0, ww = 1.0, vk = 1.0, wk = 1.0;
+        for (int j = B - 1; j >= 0; j--) { vk = vk * xr[j]; v = v + vk; }
+        vk = vk * x2; v = v + vk;
+        vk = vk * x1; v = v + vk;
+        for (int j = A - 1; j >= 0; j--) { vk = vk * xl[j]; v = v + vk; }
+        for (int j = 0; j < A; j++) { wk = wk * xl[j]; ww = ww + wk; }
+        wk = wk * x1; ww = ww + wk;
+        wk = wk * x2; ww = ww + wk;
+        for (int j = 0; j < B; j++) { wk = wk * xr[j]; ww = ww + wk; }
+        b = 1.0 / (v * ww);
+    }
+    double f = (id == 2) ? 2 * a * b : 2 * a;
+    for (int j = 0; j < A; j++) f = f * wl[j];
+    f = f * w1; f = f * w2;
+    for (int j = 0; j < B; j++) f = f * wr[j];
+    a = f;
+    // ---- fiber store, amax, residual, arg-max: as k_halfstep_de ----
+    const int u_ = iscol ? pv : vmode, v_ = iscol ? vmode : pv;        // col: (i, j) ; row: (k, q), 0-based
+    const int t = iscol ? (u_ + r0 * v_) : (u_ + n2 * v_);
+    if (live) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
+    const double mx = wave_max(live ? fabs(a) : 0.0);
+    if (lane == 0 && mode != 1) atomic_max_pos(&gs.amax, mx);          // :531 / :564
+    if (resid) {
+        const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+        double bb = a, ab = -1.0; int bi = INT_MAX;
+        if (live) {
+            if (iscol) {   // dgemv 'n', alpha=-1 (:538)
+                const double *c = Cp + u_ + (size_t)P.RM * v_;
+                const double *xq = Wq + (c_kk - 1) + (size_t)P.NM * (c_qq - 1);
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) bb = bb + (-xq[P.SW * s]) * c[P.SS * s];
+            } else {       // dgemv 't', alpha=-1 (:571)
+                const double *wvp = Wq + u_ + (size_t)P.NM * v_;
+                const double *xc = Cp + (c_ii - 1) + (size_t)P.RM * (c_jj - 1);
+                double tt = 0.0;
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) tt = tt + wvp[P.SW * s] * xc[P.SS * s];
+                bb = bb + (-1.0) * tt;
+            }
+            ab = fabs(bb); bi = t;
+        }
+        wave_argmax(ab, bb, bi);
+        if (lane == 0) { Partial pr; pr.absmax = ab; pr.val = bb; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][w] = pr; }
+    }
+    DET_ACC(9);
+}
+#undef UNI

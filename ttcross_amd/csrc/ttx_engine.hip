@@ -138,6 +138,7 @@ struct ttx_engine {
     int de_v5 = 0; size_t lds_de5 = 0;  // ... as a relay of four waves (k_halfstep_de5): the default where it fits
     int de5_fallbacks = 0;
     int de_slots = 0; size_t lds_de = 0;
+    int de_team = 0, de_team_units = 256, det_fallbacks = 0; size_t lds_det = 0;   // ... by a team of 14 waves per unit (k_halfstep_det) while the ranks are small
     int lot_rows = 0; size_t lds_der = 0;   // ... four candidates per wave, one per DPP row (k_lottery_eval_de_rows)
     int lot_wave = 0;                       // Ising D/E: lottery candidates and boundary corners by the row-wise wave evaluator (ttx_de.h)
     int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
@@ -396,6 +397,9 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         h->lds_de = sizeof(double) * (5 * (size_t)(((d + 7) & ~7) + 8) + 128);
         h->de_v2 = cfg->pivoting >= 0 && h->de_slots <= TTX_MAXPART && h->lds_de <= 150 * 1024 &&
                    !(getenv("TTX_DE_V2") && atoi(getenv("TTX_DE_V2")) == 0);
+        h->lds_det = sizeof(double) * det_lds_doubles(d);
+        h->de_team = h->de_v2 && h->lds_det <= 150 * 1024 && !(getenv("TTX_DE_TEAM") && atoi(getenv("TTX_DE_TEAM")) == 0);
+        if (getenv("TTX_DE_TEAM_UNITS")) h->de_team_units = atoi(getenv("TTX_DE_TEAM_UNITS"));
         h->lds_de5 = sizeof(double) * de5_lds_doubles(d);
         h->de_v5 = h->de_v2 && de5_fits(d) && h->lds_de5 <= 150 * 1024 && getenv("TTX_DE_V5") && atoi(getenv("TTX_DE_V5")) == 1;
     }
@@ -1047,6 +1051,9 @@ static int run_impl(ttx_engine *h)
         static size_t a_de0 = 0, a_de1 = 0;
         if (h->de_v2 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<true>), h->lds_de, a_de0)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<false>), h->lds_de, a_de1)))) return rc;
+        static size_t a_dt0 = 0, a_dt1 = 0;
+        if (h->de_team && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_det<true>), h->lds_det, a_dt0)) ||
+                           (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_det<false>), h->lds_det, a_dt1)))) return rc;
         static size_t a_d50 = 0, a_d51 = 0;
         if (h->de_v5 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de5<true>), h->lds_de5, a_d50)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de5<false>), h->lds_de5, a_d51)))) return rc;
@@ -1171,8 +1178,14 @@ static int run_impl(ttx_engine *h)
                 if (FUN == FUN_MVN && h->mvn_v2) {
                     for (int hh = 0; hh < h->H; hh++) hipLaunchKernelGGL(k_halfstep_mvn, dim3(h->de_slots, G), dim3(64), h->lds_mvn, st, P, hh, dir, h->mode);
                 } else if (FUN == FUN_ISING && h->de_v2) {
+                    // while the ranks are small (at most it_ + 1 during sweep it_) a unit gets a team of 14 waves on a CU of its own
+                    const int rb = std::min((int)h->RM, it_ + 1), team_slots = rb * ((h->NM + 63) / 64);
+                    const bool team = h->de_team && !h->de_v5 && team_slots * G <= h->de_team_units;
                     for (int hh = 0; hh < h->H; hh++) {
-                        if (h->de_v5) {
+                        if (team) {
+                            if (P.de_unit) hipLaunchKernelGGL((k_halfstep_det<true>), dim3(team_slots, G), dim3(64 * DET_NW), h->lds_det, st, P, hh, dir, h->mode);
+                            else hipLaunchKernelGGL((k_halfstep_det<false>), dim3(team_slots, G), dim3(64 * DET_NW), h->lds_det, st, P, hh, dir, h->mode);
+                        } else if (h->de_v5) {
                             if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de5<true>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
                             else hipLaunchKernelGGL(k_halfstep_de5<false>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
                         } else if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de<true>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
@@ -1372,6 +1385,18 @@ extern "C" int ttx_run(ttx_engine *h)
                 h->cluster = 0; h->cluster_aborted = false; h->cluster_fallbacks++;
                 for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
                 rc = run_impl<FUN_ISING>(h);
+            }
+            if (!rc && h->de_team && !h->de_v5) {
+                // k_halfstep_det found more units than the grid the host sized from its bound on the ranks (never expected):
+                // nothing of the run is kept, the teams are retired for this engine and the run is repeated
+                int faults = 0;
+                HIPCHECK(hipMemcpy(&faults, h->P.ctl + 3, sizeof(int), hipMemcpyDeviceToHost));
+                if (faults) {
+                    if (h->W > 1) return fail(TTX_EHIP, "ttx_run: k_halfstep_det met a rank above the host's bound; set TTX_DE_TEAM=0");
+                    h->de_team = 0; h->det_fallbacks++;
+                    for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
+                    rc = run_impl<FUN_ISING>(h);
+                }
             }
             if (!rc && h->de_v5) {
                 // the relay of k_halfstep_de5 reports a broken hand-over (bounded waits) in ctl[3]: nothing of such a run is
