@@ -469,7 +469,7 @@ def main():
         return
     path = tt.sweep_path()
     # the chain path's half-step kernel by integrand: the wave-per-pivot kernels of Ising D/E and mvn, the generic one otherwise
-    chain_k = "k_halfstep_de" if (argv[0] == "ising" and argv[1] in ("d", "e")) else "k_halfstep_mvn" if argv[0] == "mvn" else "k_halfstep"
+    chain_k = "k_halfstep_de / k_halfstep_det" if (argv[0] == "ising" and argv[1] in ("d", "e")) else "k_halfstep_mvn" if argv[0] == "mvn" else "k_halfstep"
     kname = {"chain": chain_k, "fused": "k_sweep_fused", "cluster": "k_sweep_cluster"}[path]
     kdesc = {"chain": chain_k + " (one rook half-step: fiber evaluation + residual + arg-max)",
              "fused": "k_sweep_fused (whole sweep of a bond group in one workgroup; bytes = its rook half-steps)",

@@ -147,13 +147,17 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
     __syncthreads();
     if (!cur.active || cur.done) { if (blockIdx.x == 0 && lane == 0) gs.S[h + 1] = cur; return; }
     const bool iscol = (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
-    const int p = cur.p, r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, n1 = cur.n1, n2 = cur.n2, first = gs.first;
+    // what steers the control flow is made wave-uniform explicitly (values read from LDS / global memory are per-lane
+    // registers to the compiler: loop counters and branches would otherwise run on the vector unit)
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+    const int p = UNI(cur.p), r0 = UNI(cur.r0), r1 = UNI(cur.r1), r2 = UNI(cur.r2), n1 = UNI(cur.n1), n2 = UNI(cur.n2), first = UNI(gs.first);
+    const int c_ii = UNI(cur.ii), c_jj = UNI(cur.jj), c_kk = UNI(cur.kk), c_qq = UNI(cur.qq);
     const int nf = iscol ? r0 * n1 : n2 * r2;
     const int nv = iscol ? r0 : r2, nm = iscol ? n1 : n2, nch = (nm + 63) >> 6;
     const int npart = nv * nch;
     const int w = blockIdx.x;
-    const int crs = cur.crs + 1;
-    const int havecol = cur.havecol | (iscol ? 1 : 0), haverow = cur.haverow | (iscol ? 0 : 1);
+    const int crs = UNI(cur.crs) + 1;
+    const int havecol = UNI(cur.havecol) | (iscol ? 1 : 0), haverow = UNI(cur.haverow) | (iscol ? 0 : 1);
     const int done = (mode == 1 || mode == 2) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
     const bool resid = (mode == 0) && !done;
     if (w == 0 && lane == 0) {
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
     const int pv = w / nch, vmode = (w - pv * nch) * 64 + lane;        // varying pivot, mode index (0-based)
     const bool live = vmode < nm;
     const int A = p - 1, B = m - p - 1;
-    const int pl = iscol ? pv : cur.ii - 1, qr = iscol ? cur.qq - 1 : pv;         // left / right pivot of this wave
-    const int n1m = P.n[1];
+    const int pl = iscol ? pv : c_ii - 1, qr = iscol ? c_qq - 1 : pv;         // left / right pivot of this wave
+    const int n1m = UNI(P.n[1]);
     const double *nodes = P.par, *weights = P.par + n1m;                          // 0-based here
     // LDS: UL[VS] | xl[VS] | wl[VS] | xr[VS] | wr[VS] | ring L[64] | ring R[64]
     const int VS = ((m + 7) & ~7) + 8;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
     for (int x = lane; x < A; x += 64) { const int ix = Lt[(size_t)x * P.RM + pl] - 1; xl[x] = nodes[ix]; wl[x] = weights[ix]; }
     for (int x = lane; x < B; x += 64) { const int ix = Rt[(size_t)x * P.RM + qr] - 1; xr[x] = nodes[ix]; wr[x] = weights[ix]; }
     for (int x = lane; x <= A; x += 64) UL[x] = ULg[x];
-    const int i1 = iscol ? (live ? vmode : 0) : cur.jj - 1, i2 = iscol ? cur.kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
+    const int i1 = iscol ? (live ? vmode : 0) : c_jj - 1, i2 = iscol ? c_kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
     const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
     WStream sl, sr;
     sl.init(TLg, A * (A + 1) / 2, ringL, lane);
@@ -231,12 +235,12 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
         if (live) {
             if (iscol) {   // dgemv 'n', alpha=-1 (:538): b += (-x_s) * col(:, s), x_s = row(p+1)(s, kk, qq)
                 const double *c = Cp + u_ + (size_t)P.RM * v_;
-                const double *xq = Wq + (cur.kk - 1) + (size_t)P.NM * (cur.qq - 1);
+                const double *xq = Wq + (c_kk - 1) + (size_t)P.NM * (c_qq - 1);
 #pragma unroll 8
                 for (int s = 0; s < r1; s++) bb = bb + (-xq[P.SW * s]) * c[P.SS * s];
             } else {       // dgemv 't', alpha=-1 (:571): b += -1 * sum_s row(s, kq) * x_s, x_s = col(p)(ii, jj, s)
                 const double *wv = Wq + u_ + (size_t)P.NM * v_;
-                const double *xc = Cp + (cur.ii - 1) + (size_t)P.RM * (cur.jj - 1);
+                const double *xc = Cp + (c_ii - 1) + (size_t)P.RM * (c_jj - 1);
                 double tt = 0.0;
 #pragma unroll 8
                 for (int s = 0; s < r1; s++) tt = tt + wv[P.SW * s] * xc[P.SS * s];
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
         if (lane == 0) { Partial pr; pr.absmax = ab; pr.val = bb; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][w] = pr; }
     }
 }
+#undef UNI
 
 // b-part (id 2) and weights (test_crs_ising.f90:197-218) from per-dimension value arrays xv / wv (0-based dims)
 __device__ __forceinline__ double de_finish_vals(int id, double a, int m, const double *xv, const double *wv)
@@ -697,46 +702,67 @@ __global__ __launch_bounds__(64) void k_lottery_eval_de_rows(DevProb P)
 #define DET_ND 12                 // dividing waves
 #define DET_NW (DET_ND + 2)
 __host__ __device__ inline int det_vs(int m) { return ((m + 7) & ~7) + 8; }
-__host__ __device__ inline size_t det_lds_doubles(int m) { return (size_t)4 * det_vs(m) + 128 + (det_vs(m) + 48) + (size_t)3 * DET_ND * 4 * 64; }
+__host__ __device__ inline size_t det_lds_doubles(int m) { return (size_t)4 * det_vs(m) + 256 + (det_vs(m) + 48) + (size_t)3 * DET_ND * 4 * 64; }
 
 #define TTX_RB8LO(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 #define TTX_RB8HI(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
-// wave-uniform stream of doubles consumed in order by ONE wave, delivered by DPP row broadcasts: the 64 entries of a batch
-// are parked in the LDS ring and read back as four registers whose lane n (of every DPP row) holds entry 16 b + n.  A run
-// that starts or ends inside a block of 16 multiplies the positions outside it by 1.0 (exact) instead of branching per factor.
+// wave-uniform stream of doubles consumed in order by ONE wave, delivered by DPP row broadcasts: batches of 128 entries (two
+// per lane and load, DEPTH batches in flight) are parked in an LDS ring and read back 64 at a time as four registers whose
+// lane n (of every DPP row) holds entry 16 b + n.  A run that starts or ends inside a block of 16 multiplies the positions
+// outside it by 1.0 (exact) instead of branching per factor.
+template <int DEPTH>
 struct WStreamD {
-    const double *g; double *buf; double rA, rB, f0, f1, f2, f3; int total, nextb, rd;
-    __device__ __forceinline__ double ld(int b, int lane) const { const int ix = b * 64 + lane; return ix < total ? g[ix] : 1.0; }
+    const double *g; double *buf; double r[DEPTH][2], f0, f1, f2, f3, h0, h1, h2, h3; int total, nextb, rd; bool second;
+    __device__ __forceinline__ void ld(int b, int lane, double &x, double &y) const
+    { const int ix = b * 128 + 2 * lane; x = ix < total ? g[ix] : 1.0; y = ix + 1 < total ? g[ix + 1] : 1.0; }
     __device__ __forceinline__ void init(const double *g_, int total_, double *buf_, int lane)
-    { g = g_; total = total_; buf = buf_; rA = ld(0, lane); rB = ld(1, lane); nextb = 2; rd = 64; f0 = f1 = f2 = f3 = 1.0; }
+    {
+        g = g_; total = total_; buf = buf_; nextb = DEPTH; rd = 128; second = true; f0 = f1 = f2 = f3 = h0 = h1 = h2 = h3 = 1.0;
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) ld(k, lane, r[k][0], r[k][1]);
+    }
+    // both halves of the ring are read back right after it has been written: one LDS round trip per 128 entries
+    __device__ __forceinline__ void take128(int lane)
+    {
+        const double *q = buf + (lane & 15);
+        f0 = q[0]; f1 = q[16]; f2 = q[32]; f3 = q[48]; h0 = q[64]; h1 = q[80]; h2 = q[96]; h3 = q[112];
+    }
     __device__ __forceinline__ void refill(int lane)
     {
         __builtin_amdgcn_wave_barrier();
-        buf[lane] = rA; rA = rB; rB = ld(nextb, lane); nextb++; rd = 0;
+        buf[2 * lane] = r[0][0]; buf[2 * lane + 1] = r[0][1];
+#pragma unroll
+        for (int k = 0; k + 1 < DEPTH; k++) { r[k][0] = r[k + 1][0]; r[k][1] = r[k + 1][1]; }
+        ld(nextb, lane, r[DEPTH - 1][0], r[DEPTH - 1][1]); nextb++; rd = 0; second = false;
         __builtin_amdgcn_wave_barrier();
-        const int n = lane & 15;
-        f0 = buf[n]; f1 = buf[16 + n]; f2 = buf[32 + n]; f3 = buf[48 + n];
+        take128(lane);
         __builtin_amdgcn_wave_barrier();
     }
-    // one block of 16: entries off .. off+c-1 of register fb (positions outside the run are multiplied as 1.0)
+    // one block of 16: entries off .. off+c-1 of register fb (positions outside the run are multiplied as 1.0); the
+    // broadcasts of half a block are taken before its eight dependent multiplies
     __device__ __forceinline__ double fold(double a, double fb, int off, int c, int n) const
     {
         const double fm = (n >= off && n < off + c) ? fb : 1.0;
-#define TTX_RB_ALL(k) a = a * rowbc<k>(fm);
-        if (off < 8) { TTX_RB8LO(TTX_RB_ALL) }
-        if (off + c > 8) { TTX_RB8HI(TTX_RB_ALL) }
-#undef TTX_RB_ALL
+        if (off < 8) {
+            const double b0 = rowbc<0>(fm), b1 = rowbc<1>(fm), b2 = rowbc<2>(fm), b3 = rowbc<3>(fm), b4 = rowbc<4>(fm), b5 = rowbc<5>(fm), b6 = rowbc<6>(fm), b7 = rowbc<7>(fm);
+            a = a * b0; a = a * b1; a = a * b2; a = a * b3; a = a * b4; a = a * b5; a = a * b6; a = a * b7;
+        }
+        if (off + c > 8) {
+            const double b0 = rowbc<8>(fm), b1 = rowbc<9>(fm), b2 = rowbc<10>(fm), b3 = rowbc<11>(fm), b4 = rowbc<12>(fm), b5 = rowbc<13>(fm), b6 = rowbc<14>(fm), b7 = rowbc<15>(fm);
+            a = a * b0; a = a * b1; a = a * b2; a = a * b3; a = a * b4; a = a * b5; a = a * b6; a = a * b7;
+        }
         return a;
     }
     __device__ __forceinline__ double chain(double a, int cnt, int lane)
     {
         const int n = lane & 15;
         while (cnt > 0) {
-            if (rd == 64) refill(lane);
+            if (rd == 128) refill(lane);
             // the four registers are addressed statically (a run-time index would put them into scratch memory)
-#define TTX_DETB(b, fb) if ((rd >> 4) == b && cnt > 0) { const int off = rd & 15, c = cnt < 16 - off ? cnt : 16 - off; a = fold(a, fb, off, c, n); rd += c; cnt -= c; }
+#define TTX_DETB(b, fb) if (((rd >> 4) & 3) == b && cnt > 0) { const int off = rd & 15, c = cnt < 16 - off ? cnt : 16 - off; a = fold(a, fb, off, c, n); rd += c; cnt -= c; }
             TTX_DETB(0, f0) TTX_DETB(1, f1) TTX_DETB(2, f2) TTX_DETB(3, f3)
 #undef TTX_DETB
+            if (rd == 64 && !second) { f0 = h0; f1 = h1; f2 = h2; f3 = h3; second = true; }
         }
         return a;
     }
@@ -801,9 +827,9 @@ __global__ __launch_bounds__(64 * DET_NW) void k_halfstep_det(DevProb P, int h, 
     // rows i = 0..A+1 of the triangle, RL slots each (slot 0: pair with dim p -- absent in row A+1 --, slot 1: with dim p+1,
     // slot 2+j: with right dim j), padded to BPR blocks of 16 slots; chunk k = blocks [k NBK, (k+1) NBK) of the (A+2) BPR blocks
     const int RL = B + 2, BPR = (RL + 15) >> 4, NBT = (A + 2) * BPR, NCH = (NBT + NBK - 1) / NBK;
-    // LDS: UL[VS] | xl[VS] | wl[VS] | wr[VS] | ring L | ring R | V[VS+48] (node of slot c of a row: V[2+j] = xr[j], 0 from RL on) | 3 chunks
+    // LDS: UL[VS] | xl[VS] | wl[VS] | wr[VS] | ring L[128] | ring R[128] | V[VS+48] (node of slot c of a row: V[2+j] = xr[j], 0 from RL on) | 3 chunks
     const int VS = det_vs(m);
-    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *wr = wl + VS, *ringL = wr + VS, *ringR = ringL + 64, *V = ringR + 64, *xr = V + 2;
+    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *wr = wl + VS, *ringL = wr + VS, *ringR = ringL + 128, *V = ringR + 128, *xr = V + 2;
     double *chunks = V + VS + 48;
     const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
     const double *TLg = P.deTL + (size_t)g * tsz + (size_t)pl * NP, *TRg = P.deTR + (size_t)g * tsz + (size_t)qr * NP;
@@ -817,82 +843,117 @@ __global__ __launch_bounds__(64 * DET_NW) void k_halfstep_det(DevProb P, int h, 
     const int i1 = iscol ? (live ? vmode : 0) : c_jj - 1, i2 = iscol ? c_kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
     const double x1 = nodes[i1], x2 = nodes[i2];
     const int n16 = lane & 15;
-    WStreamD sl, sr;
+    WStreamD<2> sl;
     double a = 1.0, u = 0.0, uln = 0.0;
     int ti = 0, bc = 0;                                                // U and M: row / block-in-row of the next block to visit
+    int dbc = (wv >= 2) ? ((wv - 2) >> 2) : 0;                         // D: block-in-row of its block of the chunk
+    while (dbc >= BPR) dbc -= BPR;
     if (wv == 0) sl.init(TLg, A * (A + 1) / 2, ringL, lane);
     __syncthreads();
     if (wv == 1) uln = UL[0];
+    if (wv < 2) __builtin_amdgcn_s_setprio(3);                        // the two serial roles go first on their SIMDs
 #ifdef TTX_STAMPS
     const bool st_on = (g == DET_STAMPG % (int)gridDim.y) && w == 0;
     if (st_on && tid == 0) atomicAdd((unsigned long long *)&P.gs[0].nstamp[1], 1ull);
 #endif
     DET_T0();
-    for (int R = 0; R < NCH + 2; R++) {
-        if (wv == 1) {
+    // one loop per role (the barrier is the same hardware barrier wherever a wave executes it): registers are allocated per role
+    if (wv == 1) {
+        for (int R = 0; R < NCH + 2; R++) {
             if (R < NCH) {                                             // U: the running node products of chunk R
-                double *cb = chunks + (size_t)(R % 3) * CHS * 64 + lane;
+                // a chunk holds its slots in PAIRS: (slot 2j, slot 2j+1) of lane l at double2 index 64 j + l -- every role moves
+                // 16 bytes per lane and LDS instruction (a wave gets ~20 cycles per LDS instruction whatever its width)
+                double2 *cb = reinterpret_cast<double2 *>(chunks + (size_t)(R % 3) * CHS * 64) + lane;
                 const int nb = (NBT - R * NBK) < NBK ? (NBT - R * NBK) : NBK;
+                // all LDS reads of the round first (node values of its three blocks, the next row's start value): one wait per round
                 int lbc = bc;
-                double f = V[lbc * 16 + n16];
+                const double fA = V[lbc * 16 + n16]; if (++lbc == BPR) lbc = 0;
+                const double fB = V[lbc * 16 + n16]; if (++lbc == BPR) lbc = 0;
+                const double fC = V[lbc * 16 + n16];
+                const double ulA = UL[ti + 1], ulB = UL[ti + 2], ulC = UL[ti + 3];
+                const int ti0 = ti;
                 for (int kb = 0; kb < nb; kb++) {
-                    if (++lbc == BPR) lbc = 0;
-                    const double fnx = V[lbc * 16 + n16];              // the node values of the next block: one block ahead
+                    const double f = (kb == 0) ? fA : (kb == 1) ? fB : fC;
                     const bool head = (bc == 0), lastrow = (ti == A + 1);
-                    double *out = cb + (size_t)kb * 16 * 64;
-                    if (head) { u = uln; uln = UL[ti + 1]; }           // UL[A+1] = 1: the row that starts after dim p
+                    double2 *out = cb + (size_t)kb * 8 * 64;
+                    if (head) { u = uln; uln = (ti == ti0) ? ulA : (ti == ti0 + 1) ? ulB : ulC; }   // UL[A+1] = 1: the row that starts after dim p
                     const double m0 = head ? (lastrow ? 1.0 : x1) : rowbc<0>(f);
                     const double m1 = head ? x2 : rowbc<1>(f);
-                    u = u * m0; out[0] = (head && lastrow) ? 0.0 : u;
-                    u = u * m1; out[64] = u;
-#define TTX_U_STEP(k) u = u * rowbc<k>(f); out[k * 64] = u;
-                    TTX_U_STEP(2) TTX_U_STEP(3) TTX_U_STEP(4) TTX_U_STEP(5) TTX_U_STEP(6) TTX_U_STEP(7)
-                    TTX_RB8HI(TTX_U_STEP)
+                    double ua, ub;
+                    u = u * m0; ua = (head && lastrow) ? 0.0 : u;
+                    u = u * m1; ub = u;
+                    out[0] = make_double2(ua, ub);
+                    // the dividers of the six-slot tiles continue the chain themselves from slot 3 and slot 9, which U leaves in the
+                    // first pair of THEIR tile (pairs 2 and 5; the tiles of other waves are overwritten in the same round)
+#define TTX_U_STEP(j) u = u * rowbc<2 * j>(f); ua = u; u = u * rowbc<2 * j + 1>(f); ub = u;
+                    TTX_U_STEP(1) out[64] = make_double2(ua, ub); out[128] = make_double2(ub, 0.0);
+                    TTX_U_STEP(2) TTX_U_STEP(3) TTX_U_STEP(4) out[320] = make_double2(ub, 0.0);
+                    TTX_U_STEP(5) TTX_U_STEP(6) TTX_U_STEP(7)
 #undef TTX_U_STEP
-                    f = fnx;
                     if (++bc == BPR) { bc = 0; ti++; }
                 }
             }
             DET_ACC(3);
-        } else if (wv >= 2) {
-            // waves go round-robin to the four SIMDs: waves 4k and 4k+1 share theirs with M and U and take three slots of a
-            // block, waves 4k+2 and 4k+3 five (blocks of 16 slots = 3 + 3 + 5 + 5)
-            const int dv = wv - 2, bq = dv >> 2, role = wv & 3;         // role 0/1: 3 slots at 0 / 3 ; role 2/3: 5 slots at 6 / 11
+            __syncthreads();
+            DET_ACC(4);
+        }
+        return;
+    }
+    if (wv >= 2) {
+        for (int R = 0; R < NCH + 2; R++) {
+            // waves go round-robin to the four SIMDs: waves 4k and 4k+1 share theirs with M and U and take two slots of a
+            // block, waves 4k+2 and 4k+3 six (blocks of 16 slots = 2 + 2 + 6 + 6)
+            const int dv = wv - 2, bq = dv >> 2, role = wv & 3;         // role 0/1: pair 0 / 1 ; role 2/3: pairs 2-4 / 5-7 of the block
             const int blk = (R - 1) * NBK + bq;
             if (R >= 1 && blk < NBT) {                                 // D: its slots of block bq of chunk R-1, in place
-                double *cb = chunks + ((size_t)((R - 1) % 3) * CHS + (size_t)bq * 16) * 64 + lane;
+                double2 *cb = reinterpret_cast<double2 *>(chunks + ((size_t)((R - 1) % 3) * CHS + (size_t)bq * 16) * 64) + lane;
                 if (role < 2) {
-                    double *cp = cb + (size_t)(role * 3) * 64;
-                    double uu[3], t[3];
-#pragma unroll
-                    for (int s = 0; s < 3; s++) uu[s] = cp[s * 64];
-                    de_t2xw<FAST, 3>(uu, t);
-#pragma unroll
-                    for (int s = 0; s < 3; s++) cp[s * 64] = t[s];
+                    double2 *cp = cb + (size_t)role * 64;
+                    const double2 v = cp[0];
+                    const double uu[2] = {v.x, v.y}; double t[2];
+                    de_t2xw<FAST, 2>(uu, t);
+                    cp[0] = make_double2(t[0], t[1]);
                 } else {
-                    double *cp = cb + (size_t)(6 + (role - 2) * 5) * 64;
-                    double uu[5], t[5];
-#pragma unroll
-                    for (int s = 0; s < 5; s++) uu[s] = cp[s * 64];
-                    de_t2xw<FAST, 5>(uu, t);
-#pragma unroll
-                    for (int s = 0; s < 5; s++) cp[s * 64] = t[s];
+                    // the running products of its six slots from the last one U left behind (slot 3 / slot 9, in the first pair of its own tile),
+                    // by the node values of this block -- the same multiplications U performs for its own chain
+                    const double fV = V[dbc * 16 + n16];
+                    double2 *cp = cb + (size_t)(2 + (role - 2) * 3) * 64;
+                    double uu[6], t[6];
+                    if (role == 2) {
+                        const double us = cp[0].x;                     // slot 3
+                        uu[0] = us * rowbc<4>(fV); uu[1] = uu[0] * rowbc<5>(fV); uu[2] = uu[1] * rowbc<6>(fV);
+                        uu[3] = uu[2] * rowbc<7>(fV); uu[4] = uu[3] * rowbc<8>(fV); uu[5] = uu[4] * rowbc<9>(fV);
+                    } else {
+                        const double us = cp[0].x;                     // slot 9
+                        uu[0] = us * rowbc<10>(fV); uu[1] = uu[0] * rowbc<11>(fV); uu[2] = uu[1] * rowbc<12>(fV);
+                        uu[3] = uu[2] * rowbc<13>(fV); uu[4] = uu[3] * rowbc<14>(fV); uu[5] = uu[4] * rowbc<15>(fV);
+                    }
+                    de_t2xw<FAST, 6>(uu, t);
+                    cp[0] = make_double2(t[0], t[1]); cp[64] = make_double2(t[2], t[3]); cp[128] = make_double2(t[4], t[5]);
                 }
             }
+            if (R >= 1) { dbc += NBK; while (dbc >= BPR) dbc -= BPR; }
             if (wv == 2) DET_ACC(5);
-        } else if (R >= 2) {                                           // M: the factors of chunk R-2 into `a`, in order
-            const double *cb = chunks + (size_t)((R - 2) % 3) * CHS * 64 + lane;
+            __syncthreads();
+            if (wv == 2) DET_ACC(6);
+        }
+        return;
+    }
+    for (int R = 0; R < NCH + 2; R++) {
+        if (R >= 2) {                                                  // M: the factors of chunk R-2 into `a`, in order
+            const double2 *cb = reinterpret_cast<const double2 *>(chunks + (size_t)((R - 2) % 3) * CHS * 64) + lane;
             const int nb = (NBT - (R - 2) * NBK) < NBK ? (NBT - (R - 2) * NBK) : NBK;
-            // three buffers of half a block rotate: the loads run two half-blocks (16 multiplies) ahead of the product
-            double q0[8], q1[8], q2[8];
-#define DET_LD(q, hb) _Pragma("unroll") for (int x = 0; x < 8; x++) q[x] = cb[(size_t)((hb) * 8 + x) * 64];
+            // four buffers of half a block: the first four are loaded at the top of the round (under the tabulated run of a row
+            // head, if there is one), the last two 16 multiplies ahead -- the LDS answers slowly while 14 waves use it
+            double q0[8], q1[8], q2[8], q3[8];
+#define DET_LD(q, hb) _Pragma("unroll") for (int x = 0; x < 4; x++) { const double2 v = cb[(size_t)((hb) * 4 + x) * 64]; q[2 * x] = v.x; q[2 * x + 1] = v.y; }
 #define DET_F(q) _Pragma("unroll") for (int x = 0; x < 8; x++) a = a * q[x];
 #define DET_HEAD() if (bc == 0 && ti <= A) { DET_ACC(1); a = sl.chain(a, A - ti, lane); DET_ACC(0); }
 #define DET_NEXT() if (++bc == BPR) { bc = 0; ti++; }
-            DET_LD(q0, 0) DET_LD(q1, 1)
-            DET_HEAD() DET_LD(q2, 2) DET_F(q0) DET_LD(q0, 3) DET_F(q1) DET_NEXT()
-            if (nb > 1) { DET_HEAD() DET_LD(q1, 4) DET_F(q2) DET_LD(q2, 5) DET_F(q0) DET_NEXT() }
-            if (nb > 2) { DET_HEAD() DET_F(q1) DET_F(q2) DET_NEXT() }
+            DET_LD(q0, 0) DET_LD(q1, 1) DET_LD(q2, 2) DET_LD(q3, 3)
+            DET_HEAD() DET_F(q0) DET_LD(q0, 4) DET_F(q1) DET_LD(q1, 5) DET_NEXT()
+            if (nb > 1) { DET_HEAD() DET_F(q2) DET_F(q3) DET_NEXT() }
+            if (nb > 2) { DET_HEAD() DET_F(q0) DET_F(q1) DET_NEXT() }
 #undef DET_LD
 #undef DET_F
 #undef DET_HEAD
@@ -900,9 +961,9 @@ __global__ __launch_bounds__(64 * DET_NW) void k_halfstep_det(DevProb P, int h, 
             DET_ACC(1);
         }
         __syncthreads();
-        if (wv == 0) DET_ACC(2); else if (wv == 1) DET_ACC(4); else if (wv == 2) DET_ACC(6);
+        DET_ACC(2);
     }
-    if (wv != 0) return;
+    WStreamD<6> sr;                                                    // alone on the CU by now: six batches (768 factors) in flight
     sr.init(TRg, B * (B + 1) / 2, ringR, lane);
     a = sr.chain(a, B * (B + 1) / 2, lane);
     DET_ACC(8);
