@@ -98,6 +98,100 @@ struct WStream {
     }
 };
 
+template <int K> __device__ __forceinline__ double rowbc(double f)
+{
+    return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(f), 0x150 + K, 0xf, 0xf, false));
+}
+
+#define TTX_RB8LO(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define TTX_RB8HI(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+// wave-uniform stream of doubles consumed in order by ONE wave, delivered by DPP row broadcasts: batches of 128 entries (two
+// per lane and load, DEPTH batches in flight) are parked in an LDS ring and read back 64 at a time as four registers whose
+// lane n (of every DPP row) holds entry 16 b + n.  A run that starts or ends inside a block of 16 multiplies the positions
+// outside it by 1.0 (exact) instead of branching per factor.
+template <int DEPTH>
+struct WStreamD {
+    const double *g; double *buf; double r[DEPTH][2], f0, f1, f2, f3, h0, h1, h2, h3; int total, nextb, rd; bool second;
+    __device__ __forceinline__ void ld(int b, int lane, double &x, double &y) const
+    { const int ix = b * 128 + 2 * lane; x = ix < total ? g[ix] : 1.0; y = ix + 1 < total ? g[ix + 1] : 1.0; }
+    __device__ __forceinline__ void init(const double *g_, int total_, double *buf_, int lane)
+    {
+        g = g_; total = total_; buf = buf_; nextb = DEPTH; rd = 128; second = true; f0 = f1 = f2 = f3 = h0 = h1 = h2 = h3 = 1.0;
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) ld(k, lane, r[k][0], r[k][1]);
+    }
+    // both halves of the ring are read back right after it has been written: one LDS round trip per 128 entries
+    __device__ __forceinline__ void take128(int lane)
+    {
+        const double *q = buf + (lane & 15);
+        f0 = q[0]; f1 = q[16]; f2 = q[32]; f3 = q[48]; h0 = q[64]; h1 = q[80]; h2 = q[96]; h3 = q[112];
+    }
+    __device__ __forceinline__ void refill(int lane)
+    {
+        __builtin_amdgcn_wave_barrier();
+        buf[2 * lane] = r[0][0]; buf[2 * lane + 1] = r[0][1];
+#pragma unroll
+        for (int k = 0; k + 1 < DEPTH; k++) { r[k][0] = r[k + 1][0]; r[k][1] = r[k + 1][1]; }
+        ld(nextb, lane, r[DEPTH - 1][0], r[DEPTH - 1][1]); nextb++; rd = 0; second = false;
+        __builtin_amdgcn_wave_barrier();
+        take128(lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // one block of 16: entries off .. off+c-1 of register fb (positions outside the run are multiplied as 1.0); the
+    // broadcasts of half a block are taken before its eight dependent multiplies
+    __device__ __forceinline__ double fold(double a, double fb, int off, int c, int n) const
+    {
+        const double fm = (n >= off && n < off + c) ? fb : 1.0;
+        if (off < 8) {
+            const double b0 = rowbc<0>(fm), b1 = rowbc<1>(fm), b2 = rowbc<2>(fm), b3 = rowbc<3>(fm), b4 = rowbc<4>(fm), b5 = rowbc<5>(fm), b6 = rowbc<6>(fm), b7 = rowbc<7>(fm);
+            a = a * b0; a = a * b1; a = a * b2; a = a * b3; a = a * b4; a = a * b5; a = a * b6; a = a * b7;
+        }
+        if (off + c > 8) {
+            const double b0 = rowbc<8>(fm), b1 = rowbc<9>(fm), b2 = rowbc<10>(fm), b3 = rowbc<11>(fm), b4 = rowbc<12>(fm), b5 = rowbc<13>(fm), b6 = rowbc<14>(fm), b7 = rowbc<15>(fm);
+            a = a * b0; a = a * b1; a = a * b2; a = a * b3; a = a * b4; a = a * b5; a = a * b6; a = a * b7;
+        }
+        return a;
+    }
+    // a whole block of 16 (no mask, no tests)
+    __device__ __forceinline__ double fold16(double a, double fb) const
+    {
+        {
+            const double b0 = rowbc<0>(fb), b1 = rowbc<1>(fb), b2 = rowbc<2>(fb), b3 = rowbc<3>(fb), b4 = rowbc<4>(fb), b5 = rowbc<5>(fb), b6 = rowbc<6>(fb), b7 = rowbc<7>(fb);
+            a = a * b0; a = a * b1; a = a * b2; a = a * b3; a = a * b4; a = a * b5; a = a * b6; a = a * b7;
+        }
+        {
+            const double b0 = rowbc<8>(fb), b1 = rowbc<9>(fb), b2 = rowbc<10>(fb), b3 = rowbc<11>(fb), b4 = rowbc<12>(fb), b5 = rowbc<13>(fb), b6 = rowbc<14>(fb), b7 = rowbc<15>(fb);
+            a = a * b0; a = a * b1; a = a * b2; a = a * b3; a = a * b4; a = a * b5; a = a * b6; a = a * b7;
+        }
+        return a;
+    }
+    // one long run from a batch boundary of the stream (the tabulated tail TR, from position 0): whole batches of 128 factors
+    // without a test, the rest through chain()
+    __device__ __forceinline__ double chain_from_boundary(double a, int cnt, int lane)
+    {
+        while (cnt >= 128 && rd == 128) {
+            refill(lane);
+            a = fold16(a, f0); a = fold16(a, f1); a = fold16(a, f2); a = fold16(a, f3);
+            a = fold16(a, h0); a = fold16(a, h1); a = fold16(a, h2); a = fold16(a, h3);
+            rd = 128; second = true; cnt -= 128;
+        }
+        return chain(a, cnt, lane);
+    }
+    __device__ __forceinline__ double chain(double a, int cnt, int lane)
+    {
+        const int n = lane & 15;
+        while (cnt > 0) {
+            if (rd == 128) refill(lane);
+            // the four registers are addressed statically (a run-time index would put them into scratch memory)
+#define TTX_DETB(b, fb) if (((rd >> 4) & 3) == b && cnt > 0) { const int off = rd & 15, c = cnt < 16 - off ? cnt : 16 - off; a = (c == 16) ? fold16(a, fb) : fold(a, fb, off, c, n); rd += c; cnt -= c; }
+            TTX_DETB(0, f0) TTX_DETB(1, f1) TTX_DETB(2, f2) TTX_DETB(3, f3)
+#undef TTX_DETB
+            if (rd == 64 && !second) { f0 = h0; f1 = h1; f2 = h2; f3 = h3; second = true; }
+        }
+        return a;
+    }
+};
+
 #ifndef DE_RUNW
 #define DE_RUNW 8        // division chains interleaved per batch (16 measured 1 % faster on D_256: not worth the registers)
 #endif
@@ -177,9 +271,9 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
     const int pl = iscol ? pv : c_ii - 1, qr = iscol ? c_qq - 1 : pv;         // left / right pivot of this wave
     const int n1m = UNI(P.n[1]);
     const double *nodes = P.par, *weights = P.par + n1m;                          // 0-based here
-    // LDS: UL[VS] | xl[VS] | wl[VS] | xr[VS] | wr[VS] | ring L[64] | ring R[64]
+    // LDS: UL[VS] | xl[VS] | wl[VS] | xr[VS] | wr[VS] | ring L[128] | ring R[128]
     const int VS = ((m + 7) & ~7) + 8;
-    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *xr = wl + VS, *wr = xr + VS, *ringL = wr + VS, *ringR = ringL + 64;
+    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *xr = wl + VS, *wr = xr + VS, *ringL = wr + VS, *ringR = ringL + 128;
     const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
     const double *TLg = P.deTL + (size_t)g * tsz + (size_t)pl * NP, *TRg = P.deTR + (size_t)g * tsz + (size_t)qr * NP;
     const double *ULg = P.deUL + ((size_t)g * P.RM + pl) * (m + 1);
@@ -189,7 +283,7 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
     for (int x = lane; x <= A; x += 64) UL[x] = ULg[x];
     const int i1 = iscol ? (live ? vmode : 0) : c_jj - 1, i2 = iscol ? c_kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
     const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
-    WStream sl, sr;
+    WStreamD<2> sl, sr;                                                // tabulated factors by DPP row broadcasts (end of round 2; LDS broadcasts before)
     sl.init(TLg, A * (A + 1) / 2, ringL, lane);
     sr.init(TRg, B * (B + 1) / 2, ringR, lane);
     __syncthreads();
@@ -202,7 +296,7 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
         de_run<FAST>(a, u, x2, xr, B);
     }
     de_run<FAST>(a, 1.0, x2, xr, B);                                   // i = A+1: starts after dim p
-    a = sr.chain(a, B * (B + 1) / 2, lane);
+    a = sr.chain_from_boundary(a, B * (B + 1) / 2, lane);
     // ---- b-part (id 2) and the weights (:197-218), order of de_finish ----
     const int id = P.ising_id;
     double b = 0.0;
@@ -495,10 +589,6 @@ __global__ __launch_bounds__(64 * DE5_W) void k_halfstep_de5(DevProb P, int h, i
 // The order of all products is that of de_pairs_tab (the reference's row-major pair loop), the operations per factor those
 // of de_t2: bit-identical.
 // ------------------------------------------------------------------------------------------------------------------
-template <int K> __device__ __forceinline__ double rowbc(double f)
-{
-    return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(f), 0x150 + K, 0xf, 0xf, false));
-}
 #define TTX_RB16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 // a = a * (factor of lane off) * ... * (factor of lane off+c-1) of every DPP row; off, c wave-uniform
 __device__ __forceinline__ double row_fold16(double a, double f, int off, int c)
@@ -704,70 +794,6 @@ __global__ __launch_bounds__(64) void k_lottery_eval_de_rows(DevProb P)
 __host__ __device__ inline int det_vs(int m) { return ((m + 7) & ~7) + 8; }
 __host__ __device__ inline size_t det_lds_doubles(int m) { return (size_t)4 * det_vs(m) + 256 + (det_vs(m) + 48) + (size_t)3 * DET_ND * 4 * 64; }
 
-#define TTX_RB8LO(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
-#define TTX_RB8HI(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
-// wave-uniform stream of doubles consumed in order by ONE wave, delivered by DPP row broadcasts: batches of 128 entries (two
-// per lane and load, DEPTH batches in flight) are parked in an LDS ring and read back 64 at a time as four registers whose
-// lane n (of every DPP row) holds entry 16 b + n.  A run that starts or ends inside a block of 16 multiplies the positions
-// outside it by 1.0 (exact) instead of branching per factor.
-template <int DEPTH>
-struct WStreamD {
-    const double *g; double *buf; double r[DEPTH][2], f0, f1, f2, f3, h0, h1, h2, h3; int total, nextb, rd; bool second;
-    __device__ __forceinline__ void ld(int b, int lane, double &x, double &y) const
-    { const int ix = b * 128 + 2 * lane; x = ix < total ? g[ix] : 1.0; y = ix + 1 < total ? g[ix + 1] : 1.0; }
-    __device__ __forceinline__ void init(const double *g_, int total_, double *buf_, int lane)
-    {
-        g = g_; total = total_; buf = buf_; nextb = DEPTH; rd = 128; second = true; f0 = f1 = f2 = f3 = h0 = h1 = h2 = h3 = 1.0;
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) ld(k, lane, r[k][0], r[k][1]);
-    }
-    // both halves of the ring are read back right after it has been written: one LDS round trip per 128 entries
-    __device__ __forceinline__ void take128(int lane)
-    {
-        const double *q = buf + (lane & 15);
-        f0 = q[0]; f1 = q[16]; f2 = q[32]; f3 = q[48]; h0 = q[64]; h1 = q[80]; h2 = q[96]; h3 = q[112];
-    }
-    __device__ __forceinline__ void refill(int lane)
-    {
-        __builtin_amdgcn_wave_barrier();
-        buf[2 * lane] = r[0][0]; buf[2 * lane + 1] = r[0][1];
-#pragma unroll
-        for (int k = 0; k + 1 < DEPTH; k++) { r[k][0] = r[k + 1][0]; r[k][1] = r[k + 1][1]; }
-        ld(nextb, lane, r[DEPTH - 1][0], r[DEPTH - 1][1]); nextb++; rd = 0; second = false;
-        __builtin_amdgcn_wave_barrier();
-        take128(lane);
-        __builtin_amdgcn_wave_barrier();
-    }
-    // one block of 16: entries off .. off+c-1 of register fb (positions outside the run are multiplied as 1.0); the
-    // broadcasts of half a block are taken before its eight dependent multiplies
-    __device__ __forceinline__ double fold(double a, double fb, int off, int c, int n) const
-    {
-        const double fm = (n >= off && n < off + c) ? fb : 1.0;
-        if (off < 8) {
-            const double b0 = rowbc<0>(fm), b1 = rowbc<1>(fm), b2 = rowbc<2>(fm), b3 = rowbc<3>(fm), b4 = rowbc<4>(fm), b5 = rowbc<5>(fm), b6 = rowbc<6>(fm), b7 = rowbc<7>(fm);
-            a = a * b0; a = a * b1; a = a * b2; a = a * b3; a = a * b4; a = a * b5; a = a * b6; a = a * b7;
-        }
-        if (off + c > 8) {
-            const double b0 = rowbc<8>(fm), b1 = rowbc<9>(fm), b2 = rowbc<10>(fm), b3 = rowbc<11>(fm), b4 = rowbc<12>(fm), b5 = rowbc<13>(fm), b6 = rowbc<14>(fm), b7 = rowbc<15>(fm);
-            a = a * b0; a = a * b1; a = a * b2; a = a * b3; a = a * b4; a = a * b5; a = a * b6; a = a * b7;
-        }
-        return a;
-    }
-    __device__ __forceinline__ double chain(double a, int cnt, int lane)
-    {
-        const int n = lane & 15;
-        while (cnt > 0) {
-            if (rd == 128) refill(lane);
-            // the four registers are addressed statically (a run-time index would put them into scratch memory)
-#define TTX_DETB(b, fb) if (((rd >> 4) & 3) == b && cnt > 0) { const int off = rd & 15, c = cnt < 16 - off ? cnt : 16 - off; a = fold(a, fb, off, c, n); rd += c; cnt -= c; }
-            TTX_DETB(0, f0) TTX_DETB(1, f1) TTX_DETB(2, f2) TTX_DETB(3, f3)
-#undef TTX_DETB
-            if (rd == 64 && !second) { f0 = h0; f1 = h1; f2 = h2; f3 = h3; second = true; }
-        }
-        return a;
-    }
-};
-
 #ifdef TTX_STAMPS
 #ifndef DET_STAMPG
 #define DET_STAMPG 3
@@ -965,7 +991,7 @@ __global__ __launch_bounds__(64 * DET_NW) void k_halfstep_det(DevProb P, int h, 
     }
     WStreamD<6> sr;                                                    // alone on the CU by now: six batches (768 factors) in flight
     sr.init(TRg, B * (B + 1) / 2, ringR, lane);
-    a = sr.chain(a, B * (B + 1) / 2, lane);
+    a = sr.chain_from_boundary(a, B * (B + 1) / 2, lane);
     DET_ACC(8);
     const double w1 = weights[i1], w2 = weights[i2];
     // ---- b-part (id 2) and the weights (:197-218), order of de_finish ----

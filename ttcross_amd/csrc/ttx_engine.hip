@@ -394,7 +394,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         for (int j = 0; j < cfg->n[0]; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) P.de_unit = 0;
         if (getenv("TTX_DE_FASTDIV") && atoi(getenv("TTX_DE_FASTDIV")) == 0) P.de_unit = 0;
         h->de_slots = (int)RM * ((NM + 63) / 64);
-        h->lds_de = sizeof(double) * (5 * (size_t)(((d + 7) & ~7) + 8) + 128);
+        h->lds_de = sizeof(double) * (5 * (size_t)(((d + 7) & ~7) + 8) + 256);
         h->de_v2 = cfg->pivoting >= 0 && h->de_slots <= TTX_MAXPART && h->lds_de <= 150 * 1024 &&
                    !(getenv("TTX_DE_V2") && atoi(getenv("TTX_DE_V2")) == 0);
         h->lds_det = sizeof(double) * det_lds_doubles(d);
