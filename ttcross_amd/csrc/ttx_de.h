@@ -903,19 +903,24 @@ __global__ __launch_bounds__(64 * DET_NW) void k_halfstep_det(DevProb P, int h, 
                     const bool head = (bc == 0), lastrow = (ti == A + 1);
                     double2 *out = cb + (size_t)kb * 8 * 64;
                     if (head) { u = uln; uln = (ti == ti0) ? ulA : (ti == ti0 + 1) ? ulB : ulC; }   // UL[A+1] = 1: the row that starts after dim p
-                    const double m0 = head ? (lastrow ? 1.0 : x1) : rowbc<0>(f);
-                    const double m1 = head ? x2 : rowbc<1>(f);
-                    double ua, ub;
-                    u = u * m0; ua = (head && lastrow) ? 0.0 : u;
-                    u = u * m1; ub = u;
-                    out[0] = make_double2(ua, ub);
+                    // the broadcasts of half a block are named values taken before its eight dependent multiplies (written inline the
+                    // compiler funnels them through one temporary: move, multiply, move, multiply ... each waiting for the other)
+                    const double c0 = rowbc<0>(f), c1 = rowbc<1>(f), c2 = rowbc<2>(f), c3 = rowbc<3>(f), c4 = rowbc<4>(f), c5 = rowbc<5>(f), c6 = rowbc<6>(f), c7 = rowbc<7>(f);
+                    const double m0 = head ? (lastrow ? 1.0 : x1) : c0;
+                    const double m1 = head ? x2 : c1;
                     // the dividers of the six-slot tiles continue the chain themselves from slot 3 and slot 9, which U leaves in the
-                    // first pair of THEIR tile (pairs 2 and 5; the tiles of other waves are overwritten in the same round)
-#define TTX_U_STEP(j) u = u * rowbc<2 * j>(f); ua = u; u = u * rowbc<2 * j + 1>(f); ub = u;
-                    TTX_U_STEP(1) out[64] = make_double2(ua, ub); out[128] = make_double2(ub, 0.0);
-                    TTX_U_STEP(2) TTX_U_STEP(3) TTX_U_STEP(4) out[320] = make_double2(ub, 0.0);
-                    TTX_U_STEP(5) TTX_U_STEP(6) TTX_U_STEP(7)
-#undef TTX_U_STEP
+                    // first pair of THEIR tile (pairs 2 and 5; the tiles of other waves are overwritten in the same round).  The four
+                    // stores go out together at the end of the block from registers of their own: a multiply that overwrites the
+                    // data register of an LDS store still in flight waits for it (~20 cycles per store, profiles/r02_probe_dpp.txt)
+                    u = u * m0; const double s0 = (head && lastrow) ? 0.0 : u;
+                    u = u * m1; const double s1 = u;
+                    u = u * c2; const double s2 = u;
+                    u = u * c3; const double s3 = u;
+                    u = u * c4; u = u * c5; u = u * c6; u = u * c7;
+                    const double d0 = rowbc<8>(f), d1 = rowbc<9>(f), d2 = rowbc<10>(f), d3 = rowbc<11>(f), d4 = rowbc<12>(f), d5 = rowbc<13>(f), d6 = rowbc<14>(f), d7 = rowbc<15>(f);
+                    u = u * d0; u = u * d1; const double s9 = u;
+                    u = u * d2; u = u * d3; u = u * d4; u = u * d5; u = u * d6; u = u * d7;
+                    out[0] = make_double2(s0, s1); out[64] = make_double2(s2, s3); out[128] = make_double2(s3, 0.0); out[320] = make_double2(s9, 0.0);
                     if (++bc == BPR) { bc = 0; ti++; }
                 }
             }
