@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "de_kernel_variants or ising_sweep or bond_groups" > gpurun_out/team_tests.log 2>&1 || { tail -30 gpurun_out/team_tests.log; exit 1; }
 tail -3 gpurun_out/team_tests.log
 for u in ${TEAM_UNITS:-0 256 512}; do
-  TTX_DE_TEAM_UNITS=$u timeout -k 10 300 python bench.py --workload d256 --steps 1 --warmup 0 --no-extras --no-cpu-baseline > gpurun_out/team_d256_$u.json 2>gpurun_out/team_d256_$u.err
+  TTX_DE_TEAM6_UNITS=${TEAM6_UNITS:-1024} TTX_DE_TEAM_UNITS=$u timeout -k 10 300 python bench.py --workload d256 --steps 1 --warmup 0 --no-extras --no-cpu-baseline > gpurun_out/team_d256_$u.json 2>gpurun_out/team_d256_$u.err
   python - <<P
 import json
 d=json.load(open("gpurun_out/team_d256_$u.json"))

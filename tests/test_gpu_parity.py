@@ -548,9 +548,10 @@ def test_bad_bond_groups_are_refused(own):
 
 
 @pytest.mark.parametrize("env", [{"TTX_DE_FASTDIV": "0"}, {"TTX_LOTTERY_ROWS": "2"}, {"TTX_LOTTERY_WAVE": "0"}, {"TTX_DE_V5": "1"}, {"TTX_DE_V2": "0"},
-                                 {"TTX_DE_TEAM": "0"}, {"TTX_DE_TEAM_UNITS": "1000000"}, {"TTX_DE_TEAM_UNITS": "1000000", "TTX_DE_FASTDIV": "0"}],
+                                 {"TTX_DE_TEAM": "0"}, {"TTX_DE_TEAM_UNITS": "1000000"}, {"TTX_DE_TEAM_UNITS": "1000000", "TTX_DE_FASTDIV": "0"},
+                                 {"TTX_DE_TEAM_UNITS": "0", "TTX_DE_TEAM6_UNITS": "1000000"}],
                          ids=["general_division", "lottery_rows_with_tables", "lottery_lane_per_candidate", "relay_halfstep", "lane_per_element",
-                              "wave_per_unit_halfstep", "team_halfstep_always", "team_halfstep_general_division"])
+                              "wave_per_unit_halfstep", "team_halfstep_always", "team_halfstep_general_division", "six_wave_team_halfstep_always"])
 def test_ising_de_kernel_variants_bit_exact(env, monkeypatch):
     """Every selectable variant of the D/E kernels gives the oracle's bits: the IEEE division instead of the short sequence for
     nodes in [0,1], the row-wise lottery with the pivots' factor tables (default: without), the lottery and the boundary corners

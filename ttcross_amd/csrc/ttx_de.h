@@ -789,10 +789,9 @@ __global__ __launch_bounds__(64) void k_lottery_eval_de_rows(DevProb P)
 // slot without a test.  Per element every product, difference and quotient and their order are those of k_halfstep_de:
 // bit-identical.
 // ------------------------------------------------------------------------------------------------------------------
-#define DET_ND 12                 // dividing waves
-#define DET_NW (DET_ND + 2)
+// NBK blocks of 16 slots per chunk, four dividing waves per block: 3 (14 waves, one team per CU) or 1 (6 waves, several teams per CU)
 __host__ __device__ inline int det_vs(int m) { return ((m + 7) & ~7) + 8; }
-__host__ __device__ inline size_t det_lds_doubles(int m) { return (size_t)4 * det_vs(m) + 256 + (det_vs(m) + 48) + (size_t)3 * DET_ND * 4 * 64; }
+__host__ __device__ inline size_t det_lds_doubles(int m, int nbk) { return (size_t)4 * det_vs(m) + 256 + (det_vs(m) + 48) + (size_t)3 * nbk * 16 * 64; }
 
 #ifdef TTX_STAMPS
 #ifndef DET_STAMPG
@@ -804,12 +803,12 @@ __host__ __device__ inline size_t det_lds_doubles(int m) { return (size_t)4 * de
 #define DET_T0() do {} while (0)
 #define DET_ACC(slot) do {} while (0)
 #endif
-template <bool FAST>
-__global__ __launch_bounds__(64 * DET_NW) void k_halfstep_det(DevProb P, int h, int dir, int mode)
+template <bool FAST, int NBK>
+__global__ __launch_bounds__(64 * (4 * NBK + 2)) void k_halfstep_det(DevProb P, int h, int dir, int mode)
 {
     extern __shared__ __align__(16) double dyn[];
     __shared__ StepState cur;
-    constexpr int ND = DET_ND, CHS = ND * 4, NBK = CHS / 16, NT_ = 64 * DET_NW;
+    constexpr int ND = 4 * NBK, CHS = ND * 4, NT_ = 64 * (ND + 2);
     // everything that steers the control flow is made wave-uniform explicitly (values read from LDS / global memory are
     // per-lane registers to the compiler: loop counters and branches would otherwise run on the vector unit)
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
@@ -981,10 +980,10 @@ __global__ __launch_bounds__(64 * DET_NW) void k_halfstep_det(DevProb P, int h, 
 #define DET_F(q) _Pragma("unroll") for (int x = 0; x < 8; x++) a = a * q[x];
 #define DET_HEAD() if (bc == 0 && ti <= A) { DET_ACC(1); a = sl.chain(a, A - ti, lane); DET_ACC(0); }
 #define DET_NEXT() if (++bc == BPR) { bc = 0; ti++; }
-            DET_LD(q0, 0) DET_LD(q1, 1) DET_LD(q2, 2) DET_LD(q3, 3)
-            DET_HEAD() DET_F(q0) DET_LD(q0, 4) DET_F(q1) DET_LD(q1, 5) DET_NEXT()
-            if (nb > 1) { DET_HEAD() DET_F(q2) DET_F(q3) DET_NEXT() }
-            if (nb > 2) { DET_HEAD() DET_F(q0) DET_F(q1) DET_NEXT() }
+            DET_LD(q0, 0) DET_LD(q1, 1) if (NBK > 1) { DET_LD(q2, 2) DET_LD(q3, 3) }
+            DET_HEAD() DET_F(q0) if (NBK > 2) { DET_LD(q0, 4) } DET_F(q1) if (NBK > 2) { DET_LD(q1, 5) } DET_NEXT()
+            if (NBK > 1 && nb > 1) { DET_HEAD() DET_F(q2) DET_F(q3) DET_NEXT() }
+            if (NBK > 2 && nb > 2) { DET_HEAD() DET_F(q0) DET_F(q1) DET_NEXT() }
 #undef DET_LD
 #undef DET_F
 #undef DET_HEAD

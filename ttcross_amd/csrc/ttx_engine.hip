@@ -138,7 +138,8 @@ struct ttx_engine {
     int de_v5 = 0; size_t lds_de5 = 0;  // ... as a relay of four waves (k_halfstep_de5): the default where it fits
     int de5_fallbacks = 0;
     int de_slots = 0; size_t lds_de = 0;
-    int de_team = 0, de_team_units = 256, det_fallbacks = 0; size_t lds_det = 0;   // ... by a team of 14 waves per unit (k_halfstep_det) while the ranks are small
+    int de_team = 0, de_team_units = 256, det_fallbacks = 0; size_t lds_det = 0;
+    int de_team6_units = 1024; size_t lds_det6 = 0;                                      // ... and by teams of 6 waves, several per CU, for the launches above that   // ... by a team of 14 waves per unit (k_halfstep_det) while the ranks are small
     int lot_rows = 0; size_t lds_der = 0;   // ... four candidates per wave, one per DPP row (k_lottery_eval_de_rows)
     int lot_wave = 0;                       // Ising D/E: lottery candidates and boundary corners by the row-wise wave evaluator (ttx_de.h)
     int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
@@ -397,7 +398,9 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         h->lds_de = sizeof(double) * (5 * (size_t)(((d + 7) & ~7) + 8) + 256);
         h->de_v2 = cfg->pivoting >= 0 && h->de_slots <= TTX_MAXPART && h->lds_de <= 150 * 1024 &&
                    !(getenv("TTX_DE_V2") && atoi(getenv("TTX_DE_V2")) == 0);
-        h->lds_det = sizeof(double) * det_lds_doubles(d);
+        h->lds_det = sizeof(double) * det_lds_doubles(d, 3);
+        h->lds_det6 = sizeof(double) * det_lds_doubles(d, 1);
+        if (getenv("TTX_DE_TEAM6_UNITS")) h->de_team6_units = atoi(getenv("TTX_DE_TEAM6_UNITS"));
         h->de_team = h->de_v2 && h->lds_det <= 150 * 1024 && !(getenv("TTX_DE_TEAM") && atoi(getenv("TTX_DE_TEAM")) == 0);
         if (getenv("TTX_DE_TEAM_UNITS")) h->de_team_units = atoi(getenv("TTX_DE_TEAM_UNITS"));
         h->lds_de5 = sizeof(double) * de5_lds_doubles(d);
@@ -1052,8 +1055,11 @@ static int run_impl(ttx_engine *h)
         if (h->de_v2 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<true>), h->lds_de, a_de0)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<false>), h->lds_de, a_de1)))) return rc;
         static size_t a_dt0 = 0, a_dt1 = 0;
-        if (h->de_team && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_det<true>), h->lds_det, a_dt0)) ||
-                           (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_det<false>), h->lds_det, a_dt1)))) return rc;
+        if (h->de_team && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_det<true, 3>), h->lds_det, a_dt0)) ||
+                           (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_det<false, 3>), h->lds_det, a_dt1)))) return rc;
+        static size_t a_dt2 = 0, a_dt3 = 0;
+        if (h->de_team && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_det<true, 1>), h->lds_det6, a_dt2)) ||
+                           (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_det<false, 1>), h->lds_det6, a_dt3)))) return rc;
         static size_t a_d50 = 0, a_d51 = 0;
         if (h->de_v5 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de5<true>), h->lds_de5, a_d50)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de5<false>), h->lds_de5, a_d51)))) return rc;
@@ -1178,13 +1184,18 @@ static int run_impl(ttx_engine *h)
                 if (FUN == FUN_MVN && h->mvn_v2) {
                     for (int hh = 0; hh < h->H; hh++) hipLaunchKernelGGL(k_halfstep_mvn, dim3(h->de_slots, G), dim3(64), h->lds_mvn, st, P, hh, dir, h->mode);
                 } else if (FUN == FUN_ISING && h->de_v2) {
-                    // while the ranks are small (at most it_ + 1 during sweep it_) a unit gets a team of 14 waves on a CU of its own
+                    // while the ranks are small (at most it_ + 1 during sweep it_) a unit gets a team of 14 waves on a CU of its own, up to
+                    // 1024 units a team of 6 waves (three such teams fit a CU), beyond that one wave
                     const int rb = std::min((int)h->RM, it_ + 1), team_slots = rb * ((h->NM + 63) / 64);
                     const bool team = h->de_team && !h->de_v5 && team_slots * G <= h->de_team_units;
+                    const bool team6 = h->de_team && !h->de_v5 && !team && team_slots * G <= h->de_team6_units;
                     for (int hh = 0; hh < h->H; hh++) {
                         if (team) {
-                            if (P.de_unit) hipLaunchKernelGGL((k_halfstep_det<true>), dim3(team_slots, G), dim3(64 * DET_NW), h->lds_det, st, P, hh, dir, h->mode);
-                            else hipLaunchKernelGGL((k_halfstep_det<false>), dim3(team_slots, G), dim3(64 * DET_NW), h->lds_det, st, P, hh, dir, h->mode);
+                            if (P.de_unit) hipLaunchKernelGGL((k_halfstep_det<true, 3>), dim3(team_slots, G), dim3(64 * 14), h->lds_det, st, P, hh, dir, h->mode);
+                            else hipLaunchKernelGGL((k_halfstep_det<false, 3>), dim3(team_slots, G), dim3(64 * 14), h->lds_det, st, P, hh, dir, h->mode);
+                        } else if (team6) {
+                            if (P.de_unit) hipLaunchKernelGGL((k_halfstep_det<true, 1>), dim3(team_slots, G), dim3(64 * 6), h->lds_det6, st, P, hh, dir, h->mode);
+                            else hipLaunchKernelGGL((k_halfstep_det<false, 1>), dim3(team_slots, G), dim3(64 * 6), h->lds_det6, st, P, hh, dir, h->mode);
                         } else if (h->de_v5) {
                             if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de5<true>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
                             else hipLaunchKernelGGL(k_halfstep_de5<false>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
