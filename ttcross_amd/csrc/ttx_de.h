@@ -915,11 +915,14 @@ __global__ __launch_bounds__(64 * (4 * NBK + 2)) void k_halfstep_det(DevProb P, 
                     u = u * m1; const double s1 = u;
                     u = u * c2; const double s2 = u;
                     u = u * c3; const double s3 = u;
-                    u = u * c4; u = u * c5; u = u * c6; u = u * c7;
+                    u = u * c4; u = u * c5; u = u * c6; u = u * c7; const double s7 = u;
                     const double d0 = rowbc<8>(f), d1 = rowbc<9>(f), d2 = rowbc<10>(f), d3 = rowbc<11>(f), d4 = rowbc<12>(f), d5 = rowbc<13>(f), d6 = rowbc<14>(f), d7 = rowbc<15>(f);
                     u = u * d0; u = u * d1; const double s9 = u;
-                    u = u * d2; u = u * d3; u = u * d4; u = u * d5; u = u * d6; u = u * d7;
-                    out[0] = make_double2(s0, s1); out[64] = make_double2(s2, s3); out[128] = make_double2(s3, 0.0); out[320] = make_double2(s9, 0.0);
+                    u = u * d2; u = u * d3; const double s11 = u;
+                    u = u * d4; u = u * d5; u = u * d6; u = u * d7;
+                    out[0] = make_double2(s0, s1); out[64] = make_double2(s2, s3); out[128] = make_double2(s3, 0.0);
+                    if (NBK == 1) { out[256] = make_double2(s7, 0.0); out[384] = make_double2(s11, 0.0); }      // four equal tiles (below)
+                    else out[320] = make_double2(s9, 0.0);
                     if (++bc == BPR) { bc = 0; ti++; }
                 }
             }
@@ -937,7 +940,22 @@ __global__ __launch_bounds__(64 * (4 * NBK + 2)) void k_halfstep_det(DevProb P, 
             const int blk = (R - 1) * NBK + bq;
             if (R >= 1 && blk < NBT) {                                 // D: its slots of block bq of chunk R-1, in place
                 double2 *cb = reinterpret_cast<double2 *>(chunks + ((size_t)((R - 1) % 3) * CHS + (size_t)bq * 16) * 64) + lane;
-                if (role < 2) {
+                if (NBK == 1) {
+                    // six-wave teams share their CU with other teams, no wave has a SIMD to itself: four equal tiles of four slots;
+                    // tile 0 takes its two pairs from U, the others continue the chain from slot 3 / 7 / 11 (first pair of their tile)
+                    double2 *cp = cb + (size_t)(2 * role) * 64;
+                    double uu[4], t[4];
+                    if (role == 0) { const double2 v0 = cp[0], v1 = cp[64]; uu[0] = v0.x; uu[1] = v0.y; uu[2] = v1.x; uu[3] = v1.y; }
+                    else {
+                        const double fV = V[dbc * 16 + n16];
+                        const double us = cp[0].x;
+                        if (role == 1) { uu[0] = us * rowbc<4>(fV); uu[1] = uu[0] * rowbc<5>(fV); uu[2] = uu[1] * rowbc<6>(fV); uu[3] = uu[2] * rowbc<7>(fV); }
+                        else if (role == 2) { uu[0] = us * rowbc<8>(fV); uu[1] = uu[0] * rowbc<9>(fV); uu[2] = uu[1] * rowbc<10>(fV); uu[3] = uu[2] * rowbc<11>(fV); }
+                        else { uu[0] = us * rowbc<12>(fV); uu[1] = uu[0] * rowbc<13>(fV); uu[2] = uu[1] * rowbc<14>(fV); uu[3] = uu[2] * rowbc<15>(fV); }
+                    }
+                    de_t2xw<FAST, 4>(uu, t);
+                    cp[0] = make_double2(t[0], t[1]); cp[64] = make_double2(t[2], t[3]);
+                } else if (role < 2) {
                     double2 *cp = cb + (size_t)role * 64;
                     const double2 v = cp[0];
                     const double uu[2] = {v.x, v.y}; double t[2];
