@@ -32,6 +32,9 @@ extern "C" {
 #define TTX_FUN_MVN 3      /* integrand -> mvn_pdf, test_crs_mvn.f90:156-172, lib/mvn_pdf.f90:63-83       */
 #define TTX_FUN_HOST 4     /* any user `fun` (lib/dmrgg.f90:18), evaluated on the HOST: ttx_set_integrand_host */
 
+#define TTX_ARITH_EXACT 0
+#define TTX_ARITH_FAST 1
+
 typedef struct ttx_engine ttx_engine;
 
 /* Arguments of dtt_dmrgg(arg, fun, par, accuracy, maxrank, mybonds, pivoting, neval, quad, tru),
@@ -56,7 +59,10 @@ typedef struct ttx_config {
     int32_t world_rank;     /* this process within the multi-GPU job (0 when single process)         */
     int32_t world_size;     /* number of processes (GPUs); groups are split contiguously over them   */
     int32_t verbose;        /* 1: print the reference's per-sweep log lines (lib/dmrgg.f90:971-1008) */
-    int32_t use_graph;      /* reserved (the sweep is GPU-bound back to back; graph replay is not used)   */
+    int32_t arith;          /* TTX_ARITH_EXACT (0, default): every fp64 operation of the integrand in the reference's order,
+                             * results bit-identical to the reference restatement; TTX_ARITH_FAST (1): products / sums of the
+                             * O(d^2) integrands (Ising D/E, mvn) re-associated, O(d) per fiber element, results equal to
+                             * rounding (tolerance-checked).  The environment variable TTX_ARITH=fast|exact overrides 0.     */
 } ttx_config;
 
 /* one line of the reference's per-sweep report (lib/dmrgg.f90:971-1008) */
@@ -182,6 +188,9 @@ int ttx_set_profile(ttx_engine *h, int on);
  * 0 multi-kernel chain (k_lottery / k_halfstep / k_accept per bond), 1 one workgroup per bond group for the whole
  * sweep (k_sweep_fused), 2 a cluster of workgroups per bond group for the whole sweep (k_sweep_cluster) */
 int ttx_sweep_path(const ttx_engine *h);
+/* the arithmetic this engine evaluates its integrand with (TTX_ARITH_*): FAST only where ttx_config.arith / TTX_ARITH asked for
+ * it AND the integrand has a re-associated evaluator (Ising D/E with all nodes in [0,1], mvn); everything else runs exact */
+int ttx_arith(const ttx_engine *h);
 /* runs of this engine that were replayed on the multi-kernel chain because a wait inside the cluster kernel timed out
  * (its workgroups must all be resident at once; the launch is cooperative and gated by the occupancy calculator, so this
  * is a safety net: after a fallback the engine stays on the chain path; results are identical on every path) */
@@ -202,6 +211,9 @@ int ttx_k_residual_bench(int32_t device, int64_t m, int32_t r, int32_t iters, do
 /* K1: batch integrand evaluation, ind = npts x d (row-major, 1-based indices) */
 int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
                const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out);
+/* the same with the arithmetic named (TTX_ARITH_FAST: the re-associated one-thread evaluator of ttx_fast.h; Ising D/E, nodes in [0,1]) */
+int ttx_k_eval_arith(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
+                     const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out, int32_t arith);
 /* lottery2 (lib/rnd.f90:105-126) with unit weights except zero at the listed 1-based positions */
 int ttx_k_lottery(int32_t device, int32_t npnt, int32_t m, int32_t n, int32_t nz, const int32_t *zcol,
                   const int32_t *zrow, uint64_t rngpos, int32_t *points /* [2*npnt] */);

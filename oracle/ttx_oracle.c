@@ -200,6 +200,12 @@ static double powi(double a, int b)
 }
 
 static ttxo_user_fun g_user;        /* set by ttxo_dmrgg / ttxo_accchk from ttxo_problem.user (the oracle is single-threaded) */
+/* Optional shortcut for the long fixture runs (tests/golden/make_oracle_fixture.py), OFF by default.  With every node in
+ * [0,1] the running product uij of test_crs_ising.f90:188-192 never grows, and once uij <= 2^-54 the factor is EXACTLY 1 in
+ * fp64: uij-1 rounds to -1, uij+1 rounds to 1, (-1/1)**2 = 1, a*1 = a.  Leaving the rest of the row out therefore changes
+ * no bit of the result (tests/test_oracle_golden.py::test_unit_skip_changes_no_bit); at D_256 it leaves ~12 % of the pairs. */
+static int g_unit_skip = 0;
+void ttxo_set_unit_skip(int on) { g_unit_skip = on; }
 double ttxo_fun(int fun_id, int m, const int32_t *ind, const int32_t *n, const double *par, const double *aux)
 {
     if (fun_id == TTXO_FUN_USER) { int32_t mm = m; return g_user(&mm, ind, n, par); }
@@ -211,10 +217,13 @@ double ttxo_fun(int fun_id, int m, const int32_t *ind, const int32_t *n, const d
         const double *weights = par + n1 - 1;
         double a = 1.0, b = 0.0, f;
         if (id == 2 || id == 3) {
+            int skip = g_unit_skip;
+            if (skip) for (int j = 1; j <= n1; j++) if (!(nodes[j] >= 0.0 && nodes[j] <= 1.0)) skip = 0;
             for (int i = 0; i <= m; i++) {
                 double uij = 1.0;
                 for (int j = i + 1; j <= m; j++) {
                     uij = uij * nodes[ind[j - 1]];
+                    if (skip && uij <= 0x1p-54) break;
                     double t = (uij - 1.0) / (uij + 1.0);
                     a = a * (t * t);
                 }

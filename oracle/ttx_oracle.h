@@ -106,6 +106,8 @@ void ttxo_share(int first, int last, int nproc, int32_t *own);
 void ttxo_mvn_init(int d, double r, double T, double *aux /* d + d*d + 1 */);
 /* integrand evaluation (1-based ind), test_crs_*.f90 */
 double ttxo_fun(int fun_id, int m, const int32_t *ind, const int32_t *n, const double *par, const double *aux);
+/* bit-neutral shortcut of the Ising D/E product for nodes in [0,1] (see ttx_oracle.c); off by default */
+void ttxo_set_unit_skip(int on);
 /* flang runtime random_number stream (unseeded): draw #k (0-based) */
 double ttxo_flang_draw(uint64_t k);
 /* lib/lr.f90:124-154 */

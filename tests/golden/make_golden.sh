@@ -31,6 +31,9 @@ runp 4 C 6 33 20 2
 runp 8 C 16 51 32 2
 runp 8 C 64 51 32 2
 runp 3 D 8 33 10 2
+# BASELINE config 5 at full size (about 9 minutes each on 8 cores; the result does not depend on the thread count)
+OMP_NUM_THREADS=8 run1 ising D 256 101 64 5
+runp 8 D 256 101 64 5
 # flang random_number stream (first 64 draws, hex) -- pins the RNG restatement
 cat > /tmp/ttx_rng.f90 <<'F'
 program rng

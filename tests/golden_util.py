@@ -24,7 +24,7 @@ def parse_log(txt):
 
 # golden logs whose oracle run takes minutes (single thread): compared through the stored oracle fixtures
 # tests/golden/oracle_*.npz (make_oracle_fixture.py) instead of a live oracle run
-LONG = {"mvn_128_33_50_2"}
+LONG = {"mvn_128_33_50_2", "ising_D_256_101_64_5", "ising_D_256_101_64_5_np8"}
 
 
 def golden_cases(include_long=False):

@@ -1,0 +1,178 @@
+"""TTX_ARITH=fast (ttcross_amd/csrc/ttx_fast.h): the O(d^2) integrands (Ising D/E, mvn) evaluated with re-associated products
+and sums, O(d) per fiber element.  The exact mode stays the default and the checker; parity of the fast mode is BY TOLERANCE,
+against the exact mode of the same engine (itself bit-identical to the oracle) and against the reference's golden logs:
+
+* the one-thread evaluator against the exact integrand, value by value (1e-12 relative);
+* sweeps: the same pivots over the leading sweeps, per-sweep values to 1e-11, evaluation counts to 2 %, integrals to 5e-12
+  of the exact mode where the run converges (the two modes differ by rounding only, so near-ties between symmetric
+  candidates may be broken differently -- as between the reference with MKL and the oracle with netlib sums);
+* BASELINE config 5 at full size: leading sweeps against the genuine reference's log, the integral to 1e-12 of the reference's.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from golden_util import GOLDEN, parse_log
+from ttcross_amd import drivers as D
+from ttcross_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(s, r, piv, nproc, arith):
+    return E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
+                     nproc=nproc, arith=arith).run()
+
+
+@pytest.mark.parametrize("kind,m,n", [("d", 12, 33), ("e", 40, 17), ("d", 70, 9), ("e", 6, 5)])
+def test_fast_point_evaluator_vs_exact(kind, m, n):
+    """f_ising_fast (every range [s,e] until the cut, numerator and denominator products, one division) against the reference's
+    chain of d(d+1)/2 divisions, on random multi-indices.  Values far below the largest one are left out: there the exact
+    chain runs through subnormal intermediates (a = rho^2 underflows before 2 rho b w rho does)."""
+    s = D.ising_setup(kind, m, n)
+    nn = s["n"][0]
+    rng = np.random.default_rng(7)
+    ind = rng.integers(1, nn + 1, size=(4000, m - 1)).astype(np.int32)
+    fe = E.k_eval(s["fun_id"], s["n"], s["par"], ind)
+    ff = E.k_eval(s["fun_id"], s["n"], s["par"], ind, arith="fast")
+    ok = np.abs(fe) > 1e-200 * np.abs(fe).max()
+    assert ok.sum() > 100
+    assert np.max(np.abs(ff[ok] - fe[ok]) / np.abs(fe[ok])) < 1e-12
+
+
+def test_fast_is_effective_only_where_an_evaluator_exists():
+    s = D.ising_setup("c", 8, 17)
+    assert _run(s, 6, 2, 1, "fast").arith == "exact"                       # Ising C: O(d) already
+    assert _run(D.box_setup("stdnorm", 4, 17), 6, 2, 1, "fast").arith == "exact"
+    assert _run(D.ising_setup("d", 8, 17), 6, 2, 1, "fast").arith == "fast"
+    assert _run(D.ising_setup("e", 8, 17), 6, 2, 1, None).arith == "exact"  # default
+    assert _run(D.box_setup("mvn", 5, 17), 6, 2, 1, "fast").arith == "fast"
+    s = D.ising_setup("d", 8, 17)
+    s["par"] = s["par"].copy()
+    s["par"][3] = 1.5                                                      # a node outside [0,1]: running products may grow, no cut
+    tt = _run(s, 6, 2, 1, "fast")
+    assert tt.arith == "exact"
+    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], 6, piv=2, accuracy=s["acc"], quad=s["quad"])
+    assert tt.quad(s["quad"]) == oo["value"]
+
+
+FAST_ISING = [("d", 6, 33, 12, 2, 1), ("e", 5, 33, 12, 2, 1), ("d", 12, 33, 10, 2, 1), ("d", 32, 33, 12, 2, 1), ("d", 60, 9, 6, 2, 4),
+              ("e", 9, 33, 12, 3, 7), ("d", 4, 11, 5, -1, 1), ("d", 10, 17, 8, 0, 1), ("d", 100, 17, 10, 3, 1), ("d", 64, 51, 24, 2, 8),
+              ("e", 45, 9, 6, 2, 2), ("d", 3, 21, 9, 2, 1), ("d", 4, 13, 6, 1, 2)]
+
+
+@pytest.mark.parametrize("kind,m,n,r,piv,nproc", FAST_ISING, ids=[f"{c[0]}{c[1]}_n{c[2]}_r{c[3]}_p{c[4]}_np{c[5]}" for c in FAST_ISING])
+def test_fast_ising_tracks_exact_mode(kind, m, n, r, piv, nproc):
+    s = D.ising_setup(kind, m, n)
+    a, b = _run(s, r, piv, nproc, "exact"), _run(s, r, piv, nproc, "fast")
+    assert a.arith == "exact" and b.arith == "fast"
+    ra, rb = a.sweeps(), b.sweeps()
+    assert len(ra) == len(rb)
+    ta, tb = a.tapes(), b.tapes()
+    lead = min(3, len(ra) - 1)
+    assert np.array_equal(ta[:lead, 1:a.d], tb[:lead, 1:a.d]), "pivots of the leading sweeps differ"
+    assert ra[0]["neval"] == rb[0]["neval"] and abs(ra[0]["amax"] - rb[0]["amax"]) <= 1e-12 * ra[0]["amax"]
+    for x, y in zip(ra[:lead + 1], rb[:lead + 1]):
+        assert abs(x["val"] - y["val"]) <= 1e-11 * abs(x["val"]), f"sweep {x['it']}"
+        assert abs(x["neval"] - y["neval"]) <= 0.02 * x["neval"]
+    assert abs(a.neval - b.neval) <= 0.02 * a.neval
+    va, vb = a.quad(s["quad"]), b.quad(s["quad"])
+    assert abs(va - vb) <= 5e-12 * abs(va)
+    if s["tru"]:
+        assert abs(1 - vb / s["tru"]) <= 2 * abs(1 - va / s["tru"]) + 1e-13
+    acc = b.accchk(1500) if nproc == 1 else None
+    if acc is not None and r >= 10 and piv > 0:
+        assert acc["einf"] <= max(1e-5 * acc["ainf"], 50 * a.accchk(1500)["einf"])
+
+
+FAST_MVN = [(6, 33, 12, 2, 1), (9, 17, 10, 3, 2), (5, 9, 9, 2, 1), (32, 33, 20, 2, 4), (12, 17, 8, 0, 3), (4, 11, 6, -1, 1)]
+
+
+@pytest.mark.parametrize("d,n,r,piv,nproc", FAST_MVN, ids=[f"mvn{c[0]}_n{c[1]}_r{c[2]}_p{c[3]}_np{c[4]}" for c in FAST_MVN])
+def test_fast_mvn_tracks_exact_mode(d, n, r, piv, nproc):
+    """mvn: the quadratic form from per-pivot tables (Q_L + Q_R + 2 d_L' S d_R + ...) instead of d^2 additions in order.  The
+    density is symmetric under permutations of the dimensions, so exact ties between symmetric candidates are broken by rounding
+    alone and the pivot paths of the two modes part early (as the reference's and the oracle's do, test_config4_*_vs_reference_log):
+    what must agree is the initial cross, the leading per-sweep values and the integral -- to rounding where the run converges,
+    to 1e-6 otherwise."""
+    s = D.box_setup("mvn", d, n)
+    a, b = _run(s, r, piv, nproc, "exact"), _run(s, r, piv, nproc, "fast")
+    assert b.arith == "fast"
+    ra, rb = a.sweeps(), b.sweeps()
+    assert ra[0]["neval"] == rb[0]["neval"] and abs(ra[0]["val"] - rb[0]["val"]) <= 1e-13 * abs(ra[0]["val"])
+    assert abs(ra[1]["val"] - rb[1]["val"]) <= 1e-9 * abs(ra[1]["val"])
+    assert abs(len(ra) - len(rb)) <= 2 and abs(a.neval - b.neval) <= 0.05 * a.neval
+    va, vb = a.quad(s["quad"]), b.quad(s["quad"])
+    assert abs(va - vb) <= 1e-6 * abs(va)
+    if nproc == 1 and piv > 0:       # independent check of the tables: the train built from fast values against the EXACT integrand
+        acc_a, acc_b = a.accchk(2000), b.accchk(2000)
+        assert acc_b["einf"] <= 20 * acc_a["einf"] + 1e-9 * acc_b["ainf"]
+
+
+def test_fast_mvn_values_against_the_exact_integrand():
+    """A converged mvn train (d = 9, ranks 10) built in fast mode reproduces the EXACT integrand at random points as well as the
+    exact-mode train does: dtt_accchk evaluates the reference's d^2-term sum (f_mvn) in both engines."""
+    s = D.box_setup("mvn", 9, 17)
+    a, b = _run(s, 12, 3, 1, "exact"), _run(s, 12, 3, 1, "fast")
+    ea, eb = a.accchk(4000), b.accchk(4000)           # (different samples: the RNG stream continues where each run left it)
+    assert eb["einf"] / eb["ainf"] <= 10 * ea["einf"] / ea["ainf"] + 1e-12
+    assert eb["efro"] / eb["afro"] <= 10 * ea["efro"] / ea["afro"] + 1e-12
+    assert abs(a.quad(s["quad"]) - b.quad(s["quad"])) <= 1e-12 * abs(a.quad(s["quad"]))
+
+
+def _leading_vs_log(rows, g_rows, need, vtol):
+    k = 0
+    for a, b in zip(g_rows, rows):
+        if a["erank"] == round(b["erank"], 1) and abs(a["neval"] - b["neval"]) <= 0.001 * a["neval"] and abs(a["val"] - b["val"]) <= vtol * abs(a["val"]):
+            k += 1
+        else:
+            break
+    assert k >= need, f"only {k} leading sweeps match the reference's log (need {need})"
+
+
+def test_fast_config5_d256_full_size_vs_reference():
+    """BASELINE config 5 at FULL size in fast mode (Ising D_256, n = 101, r = 64, PIV = 5), 8 bond groups on one GPU, against the
+    genuine reference's 8-rank log (tests/golden/ising_D_256_101_64_5_np8.txt): the leading sweeps (erank, n_evals to 0.1 %, val
+    to 1e-10), the integral to 1e-12 of the reference's, the number of sweeps within 4 of the reference's 38 (the accuracy rule
+    :1011-1019 fires on pivots at the rounding floor of the evaluation, which is lower in this mode), and the train against the
+    integrand at random points."""
+    g_rows, g_val, g_nev = parse_log(open(os.path.join(GOLDEN, "ising_D_256_101_64_5_np8.txt")).read())
+    s = D.ising_setup("d", 256, 101)
+    tt = _run(s, 64, 5, 8, "fast")
+    assert tt.arith == "fast"
+    rows = tt.sweeps()
+    _leading_vs_log(rows, g_rows, 6, 1e-10)
+    assert abs(len(rows) - len(g_rows)) <= 4
+    v = tt.quad(s["quad"])
+    assert abs(v - g_val) <= 1e-12 * abs(g_val)
+    assert abs(v - 0.030027620068538038) <= 1e-12 * abs(v)      # the reference's 1-rank value
+    assert abs(tt.neval - g_nev) <= 0.2 * g_nev
+    acc = tt.accchk(2000)
+    assert acc["einf"] <= 1e-9 * acc["ainf"]
+
+
+def test_fast_config4_mvn_128_full_size_vs_reference_log():
+    """BASELINE config 4 at FULL size in fast mode against the genuine reference's log.  The reference does not converge at r = 50
+    (1.2 digits) and parts ways with any other arithmetic at sweep 1 (symmetric ties, test_config4_mvn_128_full_size_vs_reference_log);
+    over sweeps 13-17 its largest pivot stays at 1.2-1.8e-13 amax, a hair above the accuracy rule's 500 eps = 1.11e-13 (:1011-1019;
+    tests/golden/oracle_mvn_128_33_50_2_np1.npz holds the same numbers for the exact mode), so whether the run stops there with
+    value 0.49 or goes on to discover more of the density (sweep 19: pivot 0.1 amax) is decided by rounding.  In fast mode the
+    rule fires at sweep 16.  What must agree: erank over the first 10 sweeps, val to 1e-9 over the first 6, n_evals to 3 % as far
+    as the run goes; and the run ends by the reference's own rule (maxrank - 1 sweeps, or three sweeps in a row with
+    pivotmax <= accuracy * amax)."""
+    g_rows, g_val, g_nev = parse_log(open(os.path.join(GOLDEN, "mvn_128_33_50_2.txt")).read())
+    s = D.box_setup("mvn", 128, 33)
+    s["aux"] = O.mvn_init(128)
+    tt = _run(s, 50, 2, 1, "fast")
+    rows = tt.sweeps()
+    assert 12 < len(rows) <= len(g_rows) == 50
+    for k, (a, b) in enumerate(zip(g_rows, rows)):
+        if k < 10:
+            assert a["erank"] == round(b["erank"], 1), f"sweep {k}"
+        if k < 6:
+            assert abs(a["val"] - b["val"]) <= 1e-9 * abs(a["val"]), f"sweep {k}"
+        assert abs(a["neval"] - b["neval"]) <= 0.03 * a["neval"], f"sweep {k}"
+    if len(rows) < 50:
+        assert all(r["pivotmax"] <= s["acc"] * r["amax"] for r in rows[-3:]), "stopped early without the accuracy rule"

@@ -66,3 +66,25 @@ def test_oracle_ising_analytic(oracle_built, m, digits):
                          capture_output=True, text=True, check=True).stdout
     d = [float(l.split(":")[1]) for l in out.splitlines() if l.startswith("correct digits")][0]
     assert d >= digits
+
+
+@pytest.mark.parametrize("kind,m,n,r,piv,nproc", [("d", 24, 17, 8, 2, 1), ("e", 30, 9, 6, 3, 3), ("d", 40, 33, 6, 1, 2)])
+def test_unit_skip_changes_no_bit(oracle_built, kind, m, n, r, piv, nproc):
+    """ttxo_set_unit_skip (used only to make the D_256 fixture in reasonable time) leaves out pair factors that are exactly 1:
+    tapes, every per-sweep record, the cores and the integral must be bit-identical with and without it."""
+    import numpy as np
+    import oracle_lib as O
+    from ttcross_amd import drivers as D
+    s = D.ising_setup(kind, m, n)
+    runs = []
+    for on in (0, 1):
+        O.lib().ttxo_set_unit_skip(on)
+        try:
+            runs.append(O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=nproc))
+        finally:
+            O.lib().ttxo_set_unit_skip(0)
+    a, b = runs
+    assert np.array_equal(a["tapes"], b["tapes"]) and a["neval"] == b["neval"] and a["value"] == b["value"]
+    assert a["sweeps"] == b["sweeps"]
+    for x, y in zip(a["cores"], b["cores"]):
+        assert np.array_equal(x, y)

@@ -23,6 +23,7 @@
 #define TTX_MAXH 24        // half-step state slots (2*piv+2 <= TTX_MAXH)
 #define TTX_MAXPART 512    // partial arg-max records per half-step (blocks per fiber)
 #define TTX_BLK 256
+#define TTX_FS 8          // rows of the per-pivot scalar tables of the fast evaluators (ttx_fast.h)
 #define XH 8             // ints in a message header
 // layout of the per-sweep summary (doubles): scalars, then initval per global group, then (r, tape[4]) per bond
 #define SUM_NEVAL 0
@@ -79,6 +80,15 @@ struct ClPart { double ab, bb, mx; int ix, pad; };
 struct DevProb {
     int d, RM, NM, G, NC;      // cores, max rank, max mode size, local groups, max cores per group
     int fun_id, piv, npar, ising_id;
+    // TTX_ARITH=fast (ttx_fast.h): the integrand may be evaluated in any association of its products and sums (results agree
+    // with the exact mode to rounding, not bit for bit).  Effective for Ising D/E with all nodes in [0,1] and for mvn; 0 elsewhere.
+    int arith;
+    // per-bond-step tables of the fast evaluators (k_fast_tables), per group; side 0 = left pivots of bond p-1, side 1 = right
+    // pivots of bond p+1.  fNear [G][FD][RM]: Ising: decay vector of a pivot (product of the t dims nearest to the bond, t = row);
+    // mvn: Y = S d (row = dimension).  fDv [G][FD][RM] (mvn): the pivot's difference vector.  fPiv [G][FS][RM]: scalars per pivot.
+    double *fNear[2], *fDv[2], *fPiv[2];
+    int FD;
+    const double *auxS;        // mvn, fast: (inv_cov + inv_cov') / 2, d x d
     int nprocs;                // global number of groups
     int has_quad;
     double mvn_norm;           // sqrt((2 pi)^d det)

@@ -143,6 +143,7 @@ struct ttx_engine {
     int lot_rows = 0; size_t lds_der = 0;   // ... four candidates per wave, one per DPP row (k_lottery_eval_de_rows)
     int lot_wave = 0;                       // Ising D/E: lottery candidates and boundary corners by the row-wise wave evaluator (ttx_de.h)
     int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
+    int fast_cap = 0;                       // TTX_ARITH=fast: rows of each decay table the lottery kernel keeps in LDS
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
     hipStream_t qstream = nullptr;      // forked per-sweep quadrature (single-process runs)
@@ -387,7 +388,37 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         HIPCHECK(hipMemcpy(dq, h->quadw.data(), sizeof(double) * h->quadw.size(), hipMemcpyHostToDevice));
     }
     P.n = dn; P.par = dpar; P.aux = daux; P.quadw = dq;
-    if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && !(getenv("TTX_DE_TABLES") && atoi(getenv("TTX_DE_TABLES")) == 0)) {
+    {   // TTX_ARITH: exact (default) or fast; fast is effective where a re-associated evaluator exists (ttx_fast.h)
+        bool want = cfg->arith == TTX_ARITH_FAST;
+        if (cfg->arith != TTX_ARITH_EXACT && cfg->arith != TTX_ARITH_FAST) { ttx_destroy(h); return fail(TTX_EINVAL, "ttx_create: arith must be TTX_ARITH_EXACT or TTX_ARITH_FAST (got %d)", cfg->arith); }
+        if (const char *e = getenv("TTX_ARITH")) {
+            const std::string v = e;
+            if (v == "fast") want = true;
+            else if (v == "exact") want = (cfg->arith == TTX_ARITH_FAST);
+            else { ttx_destroy(h); return fail(TTX_EINVAL, "TTX_ARITH must be exact or fast (got %s)", e); }
+        }
+        bool unit = true;               // Ising: all nodes in [0,1] (every running product non-increasing: the cut at 2^-54 is valid)
+        if (cfg->fun_id == TTX_FUN_ISING) for (int j = 0; j < cfg->n[0]; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) unit = false;
+        P.arith = (want && !nofun && ((cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && unit) || cfg->fun_id == TTX_FUN_MVN)) ? 1 : 0;
+        if (P.arith) {
+            P.FD = d + 1;
+            for (int sd = 0; sd < 2; sd++) {
+                A_(dev_alloc(h, &P.fNear[sd], G * (size_t)P.FD * RM));
+                A_(dev_alloc(h, &P.fPiv[sd], G * (size_t)TTX_FS * RM));
+                if (cfg->fun_id == TTX_FUN_MVN) A_(dev_alloc(h, &P.fDv[sd], G * (size_t)P.FD * RM));
+            }
+            if (cfg->fun_id == TTX_FUN_MVN) {
+                std::vector<double> sy((size_t)d * d);
+                const double *ic = h->aux.data() + d;
+                for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) sy[i + (size_t)d * j] = 0.5 * (ic[i + (size_t)d * j] + ic[j + (size_t)d * i]);
+                double *ds;
+                A_(dev_alloc(h, &ds, sy.size()));
+                HIPCHECK(hipMemcpy(ds, sy.data(), sizeof(double) * sy.size(), hipMemcpyHostToDevice));
+                P.auxS = ds;
+            }
+        }
+    }
+    if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && !P.arith && !(getenv("TTX_DE_TABLES") && atoi(getenv("TTX_DE_TABLES")) == 0)) {
         P.de_npair = d * (d + 1) / 2;
         A_(dev_alloc(h, &P.deTL, G * (size_t)P.de_npair * RM)); A_(dev_alloc(h, &P.deTR, G * (size_t)P.de_npair * RM));
         A_(dev_alloc(h, &P.deUL, G * (size_t)(d + 1) * RM));
@@ -515,6 +546,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         h->lds_half = base + (h->half_vals ? val_bytes : idx_bytes);
         const size_t dif_bytes = sizeof(double) * ((RM + 1) * VS + 4);          // mvn: rows of differences x - mu
         if (cfg->fun_id == TTX_FUN_MVN && base + dif_bytes <= 140 * 1024) { h->half_vals = 1; h->lds_half = base + dif_bytes; }
+        if (P.arith) h->lds_half = std::max(h->lds_half, base + sizeof(double) * ((size_t)std::max(P.FD, TTX_FNR) + 4 + RM + 2));   // far[] + cross terms
     }
     {
         const int nlotmax = 2 * h->RM + 2 * NM;
@@ -522,6 +554,13 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         h->lds_lot = sizeof(double) * (cfg->npar + 4) + sizeof(int) * 4 * (nlotmax + 4) + sizeof(short) * (2 * RM * VS + 16);
         const size_t lot_dif = sizeof(double) * (cfg->npar + 4) + sizeof(int) * 4 * (nlotmax + 4) + sizeof(double) * (2 * RM * VS + 4);
         if (cfg->fun_id == TTX_FUN_MVN && lot_dif <= 120 * 1024) { h->lot_vals = 1; h->lds_lot = lot_dif; }
+        if (P.arith && cfg->fun_id == TTX_FUN_ISING) {
+            // fast mode: the leading rows of the two decay tables ([row][RM] doubles each) instead of the index rows
+            const size_t hdr = sizeof(double) * (cfg->npar + 4) + sizeof(int) * 4 * (nlotmax + 4) + 32;
+            const size_t rowb = 2 * sizeof(double) * RM;
+            h->fast_cap = (int)std::min<size_t>(std::min<size_t>(40, (size_t)d + 1), hdr < 100 * 1024 ? (100 * 1024 - hdr) / rowb : 0);
+            h->lds_lot = std::max(h->lds_lot, hdr + rowb * h->fast_cap);
+        }
     }
     {   // whole-sweep kernels (Ising C): TTX_SWEEP = auto | chain | fused | cluster
         const size_t VS = ((d + 7) & ~7) + 8;
@@ -600,6 +639,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
             P.bnd_wave = 1;
             h->lds_mvn = sizeof(double) * (3 * (size_t)d + 8);
         }
+        if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && P.arith) P.bnd_wave = 1;     // boundary corners by de_fast_point_wave
         if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && P.deTL) {
             int *lcd; double *lf;
             rc = dev_alloc(h, &lcd, (size_t)h->G * nlotmax * 4); if (rc) { ttx_destroy(h); return rc; }
@@ -1160,8 +1200,16 @@ static int run_impl(ttx_engine *h)
                 KScope ks(h, TTX_K_OTHER);
                 hipLaunchKernelGGL(k_de_tables, dim3((2 * (d + 1) * h->RM + 255) / 256, G), dim3(256), 0, st, P, dir, pp);
             }
+            const bool fastk = P.arith && (FUN == FUN_MVN || (FUN == FUN_ISING && P.ising_id != 1));
+            if (fastk) {    // TTX_ARITH=fast: per-pivot tables of this bond step (ttx_fast.h)
+                KScope ks(h, TTX_K_OTHER);
+                hipLaunchKernelGGL(k_fast_tables<FUN>, dim3(2 * h->RM, G), dim3(64), sizeof(double) * 2 * (d + 8), st, P, dir, pp);
+            }
             if (h->cfg.pivoting >= 0) {
-                if (FUN == FUN_MVN && h->mvn_v2) {
+                if (fastk) {
+                    KScope ks(h, TTX_K_LOTTERY);
+                    hipLaunchKernelGGL(k_lottery<FUN>, dim3(P.lot_nb, G), dim3(P.lot_nb == 1 ? 512 : 256), h->lds_lot, st, P, dir, pp, h->fast_cap, 0);
+                } else if (FUN == FUN_MVN && h->mvn_v2) {
                     KScope ks(h, TTX_K_LOTTERY, 3);
                     hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 1);
                     hipLaunchKernelGGL(k_lottery_eval_mvn, dim3(P.lot_max, G), dim3(64), h->lds_mvn, st, P);
@@ -1181,7 +1229,9 @@ static int run_impl(ttx_engine *h)
                 } else
                 { KScope ks(h, TTX_K_LOTTERY); if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_lottery<FUN>, dim3(P.lot_nb, G), dim3(P.lot_nb == 1 ? 512 : 256), h->lds_lot, st, Q, dir, pp, h->lot_vals, 0); })) return rc_; }
                 KScope ks(h, TTX_K_HALFSTEP, h->H);
-                if (FUN == FUN_MVN && h->mvn_v2) {
+                if (fastk) {
+                    for (int hh = 0; hh < h->H; hh++) hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, hh, dir, h->mode, 0);
+                } else if (FUN == FUN_MVN && h->mvn_v2) {
                     for (int hh = 0; hh < h->H; hh++) hipLaunchKernelGGL(k_halfstep_mvn, dim3(h->de_slots, G), dim3(64), h->lds_mvn, st, P, hh, dir, h->mode);
                 } else if (FUN == FUN_ISING && h->de_v2) {
                     // while the ranks are small (at most it_ + 1 during sweep it_) a unit gets a team of 14 waves on a CU of its own, up to
@@ -1213,15 +1263,15 @@ static int run_impl(ttx_engine *h)
                 if (P.fp_mfma && FUN != FUN_HOST) {
                     // one dense step: evaluate the superblock once, residual by fp64 MFMA fused with the arg-max
                     const int side = h->RM * h->NM, gx = (side + 63) / 64;
-                    hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 4, h->half_vals);
+                    hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 4, fastk ? 0 : h->half_vals);
                     hipLaunchKernelGGL(k_full_gemm_argmax, dim3(gx, gx, G), dim3(256), 0, st, P);
                     hipLaunchKernelGGL(k_full_resolve2, dim3(G), dim3(256), 0, st, P, gx, gx);
                 } else {
-                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 3, h->half_vals);
+                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 3, fastk ? 0 : h->half_vals);
                 hipLaunchKernelGGL(k_full_resolve, dim3(G), dim3(256), 0, st, P);
                 }
-                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 2, h->half_vals);
-                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 1, dir, 2, h->half_vals);
+                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 2, fastk ? 0 : h->half_vals);
+                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 1, dir, 2, fastk ? 0 : h->half_vals);
             }
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }
@@ -2147,6 +2197,7 @@ extern "C" int ttx_ijk(ttx_engine *h, const int32_t *ind, double *val)
     return TTX_OK;
 }
 
+extern "C" int ttx_arith(const ttx_engine *h) { return h ? h->P.arith : -1; }
 extern "C" int ttx_sweep_path(const ttx_engine *h) { return !h ? -1 : h->cluster ? 2 : h->fused ? 1 : 0; }
 extern "C" int64_t ttx_resid_halfsteps(const ttx_engine *h) { return h ? h->n_resid : 0; }
 extern "C" int ttx_cluster_fallbacks(const ttx_engine *h) { return h ? h->cluster_fallbacks : 0; }
@@ -2344,8 +2395,16 @@ extern "C" int ttx_k_latency_probe(int32_t device, double out[5])
     return TTX_OK;
 }
 
+static int k_eval_impl(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
+                       const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out, int arith);
 extern "C" int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
                           const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out)
+{ return k_eval_impl(device, fun_id, d, n, par, npar, aux, naux, npts, ind, out, 0); }
+extern "C" int ttx_k_eval_arith(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
+                                const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out, int32_t arith)
+{ return k_eval_impl(device, fun_id, d, n, par, npar, aux, naux, npts, ind, out, arith); }
+static int k_eval_impl(int32_t device, int32_t fun_id, int32_t d, const int32_t *n, const double *par, int32_t npar,
+                       const double *aux, int32_t naux, int64_t npts, const int32_t *ind, double *out, int arith)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "no HIP device");
@@ -2362,6 +2421,7 @@ extern "C" int ttx_k_eval(int32_t device, int32_t fun_id, int32_t d, const int32
     if (aux && naux > 0) { HIPCHECK(hipMalloc((void **)&daux, sizeof(double) * naux)); HIPCHECK(hipMemcpy(daux, aux, sizeof(double) * naux, hipMemcpyHostToDevice)); }
     P.d = d; P.n = dn; P.par = dpar; P.aux = daux; P.npar = npar; P.fun_id = fun_id;
     P.ising_id = (fun_id == TTX_FUN_ISING) ? (int)par[2 * n[0]] : 0;
+    P.arith = (arith == TTX_ARITH_FAST && fun_id == TTX_FUN_ISING && P.ising_id != 1) ? 1 : 0;     // the one-thread evaluator f_ising_fast (nodes must lie in [0,1])
     P.mvn_norm = (fun_id == TTX_FUN_MVN) ? std::sqrt(powi(2.0 * 3.141592653589793, d) * aux[d + (size_t)d * d]) : 1.0;
     dim3 grid((unsigned)((npts + 255) / 256));
     size_t lds = sizeof(double) * (npar + 2);

@@ -37,6 +37,8 @@ __device__ __forceinline__ short *L_ptr(const DevProb &P, int g, int s, int firs
 __device__ __forceinline__ short *R_ptr(const DevProb &P, int g, int s, int first)      // bond s in first..last+1
 { return P.R + ((size_t)g * P.NC + (s - first)) * (size_t)P.d * P.RM; }
 
+#include "ttx_fast.h"     // TTX_ARITH=fast: re-associated evaluation of the heavy integrands (tolerance-checked mode)
+
 // ------------------------------------------------------------------------------------------------
 // integrands (reference drivers' callbacks).  idx(s), s = 1..m, returns the 1-based mode index of dim s.
 // ------------------------------------------------------------------------------------------------
@@ -69,6 +71,29 @@ __device__ __forceinline__ double f_ising(int id, int m, int n1, const double *p
     f = (id == 1) ? 2 * b : (id == 2) ? 2 * a * b : 2 * a;
     for (int i = 1; i <= m; i++) f = f * weights[idx(i)];
     return f;
+}
+
+// TTX_ARITH=fast, any multi-index (initial cross, boundary corners, dtt_accchk): rho by de_fast_rho, then the b-part and
+// the weights as above; f = (2 rho b w_1 ... w_m) rho keeps rho^2 out of the intermediate results (more range than a itself)
+template <class IDX>
+__device__ __forceinline__ double f_ising_fast(int id, int m, int n1, const double *par, IDX idx)
+{
+    const double *nodes = par - 1, *weights = par + n1 - 1;
+    const double rho = de_fast_rho(m, nodes, idx);
+    double b = 1.0;
+    if (id == 2) {
+        double v = 1.0, w = 1.0, vk = 1.0, wk = 1.0;
+        for (int i = 1; i <= m; i++) {
+            vk = vk * nodes[idx(m - i + 1)];
+            wk = wk * nodes[idx(i)];
+            v = v + vk;
+            w = w + wk;
+        }
+        b = 1.0 / (v * w);
+    }
+    double f = 2 * rho * b;
+    for (int i = 1; i <= m; i++) f = f * weights[idx(i)];
+    return f * rho;
 }
 
 template <class IDX>
@@ -144,7 +169,7 @@ template <int FUN, class IDX>
 __device__ __forceinline__ double eval_fun(const DevProb &P, const double *par, IDX idx, long slot = -1)
 {
     if (FUN == FUN_HOST) return f_host(P, idx, slot);
-    if (FUN == FUN_ISING) return f_ising(P.ising_id, P.d, P.n[1], par, idx);
+    if (FUN == FUN_ISING) return (P.arith && P.ising_id != 1) ? f_ising_fast(P.ising_id, P.d, P.n[1], par, idx) : f_ising(P.ising_id, P.d, P.n[1], par, idx);
     if (FUN == FUN_STDNORM) return f_stdnorm(P.d, par, idx);
     return f_mvn(P.d, par, P.aux, P.mvn_norm, idx);
 }
@@ -439,6 +464,7 @@ template <int FUN>
 __device__ __forceinline__ double eval_src4(const DevProb &P, const double *par, const Src4 &S, long slot = -1)
 {
     if (FUN == FUN_ISING && P.ising_id == 1) return f_ising_c4(P.d, P.n[1], par, S);
+    if (FUN == FUN_ISING && P.arith) return f_ising_fast(P.ising_id, P.d, P.n[1], par, S);
     if (FUN == FUN_ISING) return f_ising_de<2>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.s1, S.s2, S.pb);
     return eval_fun<FUN>(P, par, S, slot);
 }
@@ -504,6 +530,7 @@ template <int FUN, bool ALIGNED>
 __device__ __forceinline__ double eval_src3(const DevProb &P, const double *par, const Src3 &S, long slot = -1)
 {
     if (ALIGNED && FUN == FUN_ISING && P.ising_id == 1) return f_ising_c3(P.d, P.n[1], par, S);
+    if (ALIGNED && FUN == FUN_ISING && P.arith) return f_ising_fast(P.ising_id, P.d, P.n[1], par, S);
     if (ALIGNED && FUN == FUN_ISING) return f_ising_de<1>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.self, 0, S.pb);
     return eval_fun<FUN>(P, par, S, slot);
 }
@@ -1017,10 +1044,26 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
     for (int x = tid; x < P.npar; x += blockDim.x) par[x] = P.par[x];
     // mvn: rows of differences x - mu (doubles) take the place of the index rows (host sized the LDS for them: vals)
-    const bool usem = (FUN == FUN_MVN) && (vals != 0);
+    const bool fastp = fast_path(P, FUN);           // TTX_ARITH=fast: candidates from the tables of k_fast_tables (vals = LDS rows per side)
+    const bool usem = (FUN == FUN_MVN) && (vals != 0) && !fastp;
     double *DLv = (double *)(((size_t)LT + 15) & ~(size_t)15), *DRv = DLv + (size_t)r0 * VS;
+    double *sNL = DLv, *sNR = DLv + (size_t)vals * P.RM;
+    __shared__ int s_mc[2];
+    int fcap = 0;
     if (phase != 0) {
         // no evaluation in this launch: the pivot rows are not needed
+    } else if (fastp) {
+        if (FUN == FUN_ISING && vals > 0) {
+            // the leading rows of the two decay tables (those above the cut for at least one pivot, at most vals) into LDS
+            if (tid < 2) s_mc[tid] = 0;
+            __syncthreads();
+            for (int x = tid; x < r0; x += blockDim.x) atomicMax(&s_mc[0], (int)P.fPiv[0][(size_t)g * TTX_FS * P.RM + FP_N * P.RM + x]);
+            for (int x = tid; x < r2; x += blockDim.x) atomicMax(&s_mc[1], (int)P.fPiv[1][(size_t)g * TTX_FS * P.RM + FP_N * P.RM + x]);
+            __syncthreads();
+            fcap = min(vals, max(s_mc[0], s_mc[1]));
+            const double *nL = P.fNear[0] + (size_t)g * P.FD * P.RM, *nR = P.fNear[1] + (size_t)g * P.FD * P.RM;
+            for (int x = tid; x < fcap * P.RM; x += blockDim.x) { const int c = x % P.RM; sNL[x] = (c < r0) ? nL[x] : 0.0; sNR[x] = (c < r2) ? nR[x] : 0.0; }
+        }
     } else if (usem) {
         __syncthreads();
         const double *mu = P.aux;
@@ -1100,6 +1143,8 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
         double f;
         if (phase == 2) f = P.lotf[(size_t)g * P.lot_max + il];
+        else if (fastp) f = (FUN == FUN_MVN) ? mvn_fast_value(P, g, p, i - 1, j - 1, k - 1, q - 1, mvn_fast_cross(P, g, p, i - 1, q - 1))
+                                             : de_fast_elem4(P, g, i - 1, j - 1, k - 1, q - 1, sNL, sNR, fcap);
         else if (usem) f = f_mvn_rows<2>(m, P.auxT, P.mvn_norm, DLv + (size_t)(i - 1) * VS, p - 1, par[j - 1] - P.aux[p - 1], par[k - 1] - P.aux[p],
                                     DRv + (size_t)(q - 1) * VS);
         else if (FUN == FUN_ISING && P.ising_id != 1 && P.deTL) {
@@ -1214,6 +1259,37 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     const int vrows = iscol ? p - 1 : m - p - 1, vcols = iscol ? r0 : r2;
     const bool usev = (FUN == FUN_ISING) && (P.ising_id == 1) && (vals != 0);
     const int n1m = P.n[1];
+    // TTX_ARITH=fast (ttx_fast.h): the fixed side of the fiber as a decay vector far[] (Ising D/E) or the cross terms of the
+    // varying pivots with the fixed pivot (mvn), then O(small) work per element from the tables of k_fast_tables
+    const bool fastp = fast_path(P, FUN);
+    double *far = vbase, *Xv = vbase + ((max(P.FD, TTX_FNR) + 3) & ~1);
+    __shared__ int s_nfar; __shared__ double s_rfix;
+    const int fside = iscol ? 0 : 1;                                         // the varying side
+    const int vfix = iscol ? cur.qq - 1 : cur.ii - 1, xfix = iscol ? cur.kk - 1 : cur.jj - 1;   // fixed pivot (other side), fixed mode index next to the free dim
+    if (fastp && FUN == FUN_ISING) {
+        const double *nearO = P.fNear[1 - fside] + (size_t)g * P.FD * P.RM + vfix, *pO = P.fPiv[1 - fside] + (size_t)g * TTX_FS * P.RM + vfix;
+        const int cntO = (int)pO[FP_N * P.RM];
+        const double xf = P.par[xfix];
+        if (tid == 0) far[0] = 1.0;
+        for (int b = tid; b < cntO; b += TTX_BLK) far[1 + b] = xf * nearO[(size_t)b * P.RM];
+        __syncthreads();
+        if (tid < 64) {          // ranges of the fixed side that begin / end at its mode index next to the free dim; entries above the cut
+            double N = 1.0, D = 1.0; int cnt = 0;
+            for (int b0 = 1; b0 <= cntO; b0 += 64) {
+                const int b = b0 + tid;
+                const double c = (b <= cntO) ? far[b] : 0.0;
+                const bool on = c > TTX_FCUT;
+                if (on) { N = N * (1.0 - c); D = D * (1.0 + c); }
+                cnt += __popcll(__ballot(on));
+            }
+            N = wave_prod(N); D = wave_prod(D);
+            if (tid == 0) { s_nfar = 1 + cnt; s_rfix = pO[FP_T * P.RM] * (N / D); }
+        }
+    }
+    if (fastp && FUN == FUN_MVN) {
+        const int nv = iscol ? r0 : r2;
+        for (int v_ = tid; v_ < nv; v_ += TTX_BLK) Xv[v_] = iscol ? mvn_fast_cross(P, g, p, v_, vfix) : mvn_fast_cross(P, g, p, vfix, v_);
+    }
     __syncthreads();      // par is read below when staging values
     if (usev) {
         // rows: [0 .. vcols) varying index, row vcols = fixed side; each row: VS node values then VS weight values
@@ -1248,7 +1324,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     }
     short *fxs = (short *)vbase;
     short *vt = fxs + VS;
-    if (!usev && !usem) {
+    if (!usev && !usem && !fastp) {
         if (iscol) {   // varying: left pivot i (dims 1..p-1) and j; fixed: kk and the right multi-index of qq (dims p+1..m)
             for (int x = tid; x < vcols * VS; x += TTX_BLK) { const int c = x / VS, o = x % VS; vt[x] = (o < vrows) ? Lt[(size_t)o * P.RM + c] : (short)1; }
             for (int x = tid; x < VS; x += TTX_BLK) fxs[x] = (x == 0) ? (short)cur.kk : (x < m - p) ? Rt[(size_t)(x - 1) * P.RM + (cur.qq - 1)] : (short)1;
@@ -1267,7 +1343,24 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     int u = 0, v = 0;                         // col: (i,j) 0-based ; row: (k,q) 0-based
     if (live) {
         if (iscol) { u = t % r0; v = t / r0; } else { u = t % n2; v = t / n2; }
-        if (usev) {
+        if (fastp && FUN == FUN_ISING) {
+            const int pv = iscol ? u : v, nd = iscol ? v : u;                // varying pivot, free mode index (0-based)
+            const double *nearV = P.fNear[fside] + (size_t)g * P.FD * P.RM + pv, *pV = P.fPiv[fside] + (size_t)g * TTX_FS * P.RM + pv;
+            const double *pO = P.fPiv[1 - fside] + (size_t)g * TTX_FS * P.RM + vfix;
+            const double xn = par[nd], xf = par[xfix];
+            double N = 1.0, D = 1.0;
+            if (s_nfar <= TTX_FNR) {
+                FarReg C;
+                far_load(C, far, s_nfar);
+                de_fast_span_reg(nearV, (size_t)P.RM, (int)pV[FP_N * P.RM], xn, C, N, D);
+            } else
+                de_fast_span(nearV, (size_t)P.RM, (int)pV[FP_N * P.RM], xn, far, s_nfar, N, D);
+            const double rho = pV[FP_T * P.RM] * (N / D) * s_rfix;
+            a = iscol ? de_fast_value(P.ising_id, P.RM, rho, pV, xn, par[n1m + nd], xf, par[n1m + xfix], pO)
+                      : de_fast_value(P.ising_id, P.RM, rho, pO, xf, par[n1m + xfix], xn, par[n1m + nd], pV);
+        } else if (fastp && FUN == FUN_MVN) {
+            a = iscol ? mvn_fast_value(P, g, p, u, v, xfix, vfix, Xv[u]) : mvn_fast_value(P, g, p, vfix, xfix, u, v, Xv[v]);
+        } else if (usev) {
             const double *fn = vbase + (size_t)vcols * 2 * VS, *fw = fn + VS;
             if (iscol) { const double *rn = vbase + (size_t)u * 2 * VS; a = f_ising_c3v(m, p - 1, rn, rn + VS, par[v], par[n1m + v], fn, fw); }
             else       { const double *rn = vbase + (size_t)v * 2 * VS; a = f_ising_c3v(m, p, fn, fw, par[u], par[n1m + u], rn, rn + VS); }
@@ -1828,6 +1921,7 @@ __device__ __forceinline__ double de_corner_wave(const DevProb &P, const double 
     }
     if (lane < 56) xv[m + lane] = 1.0;                      // the evaluator's running products read up to 47 columns past a row's end
     __builtin_amdgcn_wave_barrier();
+    if (P.arith) return de_fast_point_wave(P.ising_id, m, xv, wv, lane);      // TTX_ARITH=fast (ttx_fast.h)
     double a = 1.0;
     if (P.de_unit) for (int i = 0; i < m; i++) a = rows_span<true>(a, 1.0, xv + i, m - i, false, n);
     else for (int i = 0; i < m; i++) a = rows_span<false>(a, 1.0, xv + i, m - i, false, n);

@@ -32,7 +32,7 @@ class _Config(ctypes.Structure):
                 ("npar", c_int32), ("aux", POINTER(c_double)), ("naux", c_int32), ("quadw", POINTER(c_double)),
                 ("accuracy", c_double), ("maxrank", c_int32), ("pivoting", c_int32), ("tru", c_double),
                 ("has_tru", c_int32), ("nproc", c_int32), ("mybonds", POINTER(c_int32)), ("device", c_int32),
-                ("world_rank", c_int32), ("world_size", c_int32), ("verbose", c_int32), ("use_graph", c_int32)]
+                ("world_rank", c_int32), ("world_size", c_int32), ("verbose", c_int32), ("arith", c_int32)]
 
 
 _SENDRECV = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, ctypes.c_int, c_void_p, c_int64, ctypes.c_int, c_void_p, c_int64)
@@ -175,7 +175,7 @@ class TTCross:
     sweep state).  n: mode sizes arg%n(1:d); quad: list/array of per-mode weight vectors (rank-1 TT)."""
 
     def __init__(self, n, fun_id, par, maxrank, pivoting=3, accuracy=None, quad=None, tru=None, aux=None,
-                 nproc=1, mybonds=None, device=0, verbose=False, use_graph=False, world_rank=0, world_size=1):
+                 nproc=1, mybonds=None, device=0, verbose=False, arith=None, world_rank=0, world_size=1):
         L = load_library()
         self._n = np.ascontiguousarray(n, dtype=np.int32)
         self.d = int(self._n.size)
@@ -203,7 +203,7 @@ class TTCross:
         c.world_rank, c.world_size = int(world_rank), int(world_size)
         self.world_rank, self.world_size = int(world_rank), int(world_size)
         c.verbose = 1 if verbose else 0
-        c.use_graph = 1 if use_graph else 0
+        c.arith = 1 if arith in (1, "fast") else 0      # None / "exact": exact unless TTX_ARITH=fast is set
         self._h = c_void_p()
         _check(L.ttx_create(ctypes.byref(self._h), ctypes.byref(c)))
 
@@ -305,6 +305,13 @@ class TTCross:
     @property
     def host_calls(self):
         return int(load_library().ttx_host_calls(self._h))
+
+    @property
+    def arith(self):
+        """'exact' or 'fast': the arithmetic the integrand is evaluated with (include/ttx.h: ttx_arith)."""
+        L = load_library()
+        L.ttx_arith.argtypes = [c_void_p]
+        return ("exact", "fast")[L.ttx_arith(self._h)]
 
     def sweep_path(self):
         """'chain', 'fused' or 'cluster': the sweep implementation chosen at creation (TTX_SWEEP)."""
@@ -464,14 +471,16 @@ def k_residual_bench(m, r, iters=20, device=0):
     return ms.value, by.value
 
 
-def k_eval(fun_id, n, par, ind, aux=None, device=0):
+def k_eval(fun_id, n, par, ind, aux=None, device=0, arith=None):
     n = np.ascontiguousarray(n, dtype=np.int32)
     par = np.ascontiguousarray(par, dtype=np.float64)
     ind = np.ascontiguousarray(ind, dtype=np.int32)
     aux_ = None if aux is None else np.ascontiguousarray(aux, dtype=np.float64)
     out = np.zeros(ind.shape[0])
-    _check(load_library().ttx_k_eval(device, fun_id, n.size, _ip(n), _dp(par), par.size, _dp(aux_), 0 if aux_ is None else aux_.size,
-                                     ind.shape[0], _ip(ind), _dp(out)))
+    L = load_library()
+    L.ttx_k_eval_arith.argtypes = L.ttx_k_eval.argtypes + [c_int32]
+    _check(L.ttx_k_eval_arith(device, fun_id, n.size, _ip(n), _dp(par), par.size, _dp(aux_), 0 if aux_ is None else aux_.size,
+                              ind.shape[0], _ip(ind), _dp(out), 1 if arith in (1, "fast") else 0))
     return out
 
 

@@ -73,7 +73,7 @@ contains
   call ttx_world(wrank,wsize)
   if(wsize.gt.1 .and. .not.present(mybonds) .and. ngroups.lt.wsize)ngroups=wsize
   cfg%nproc=ngroups
-  cfg%device=0; cfg%world_rank=wrank; cfg%world_size=wsize; cfg%verbose=1; cfg%use_graph=0
+  cfg%device=0; cfg%world_rank=wrank; cfg%world_size=wsize; cfg%verbose=1; cfg%arith=0
   call get_environment_variable('TTX_DEVICE',env,status=stat)
   if(stat.eq.0)read(env,*)cfg%device
   if(c_associated(arg%ttx))then; call ttx_destroy(arg%ttx); arg%ttx=c_null_ptr; endif

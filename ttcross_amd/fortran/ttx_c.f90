@@ -24,7 +24,7 @@ module ttx_c
   integer(c_int32_t) :: world_rank
   integer(c_int32_t) :: world_size
   integer(c_int32_t) :: verbose
-  integer(c_int32_t) :: use_graph
+  integer(c_int32_t) :: arith
  end type
  interface
   function ttx_last_error() bind(C,name='ttx_last_error') result(p)
