@@ -112,6 +112,9 @@ int ttx_comm_init_shm(ttx_engine *h, const char *name);
  * reference's `par` is optional).  The sweep logic, pivot search and factor updates stay on the device; results are
  * those of the reference for the same `fun`.  pivoting = -1 is not available in this mode. */
 typedef double (*ttx_host_fun)(const int32_t *m, const int32_t *ind, const int32_t *n, const double *par);
+/* LIFETIME: the engine keeps the two pointers, it does not copy par.  They must stay valid for every later call that evaluates
+ * (ttx_run, ttx_accchk); a caller whose par may move or die calls ttx_set_integrand_host again before such a call (the
+ * Fortran dtt_accchk does, with the fun / par it was given: lib/dmrgg.f90:1081 checks against ITS arguments). */
 int ttx_set_integrand_host(ttx_engine *h, ttx_host_fun fun, const double *par);
 int64_t ttx_host_calls(const ttx_engine *h);                      /* calls of `fun` made by the last ttx_run */
 
@@ -195,6 +198,10 @@ int ttx_arith(const ttx_engine *h);
  * (its workgroups must all be resident at once; the launch is cooperative and gated by the occupancy calculator, so this
  * is a safety net: after a fallback the engine stays on the chain path; results are identical on every path) */
 int ttx_cluster_fallbacks(const ttx_engine *h);
+/* runs of this engine that were repeated without the wave teams / the wave relay of the Ising D/E half-step because a launch
+ * reported a fault (more units than the grid the host sized, a broken hand-over); results are identical on every path */
+int ttx_det_fallbacks(const ttx_engine *h);
+int ttx_fun_id(const ttx_engine *h);                /* TTX_FUN_* the engine was created with (0: a loaded train without integrand) */
 int64_t ttx_resid_halfsteps(const ttx_engine *h);   /* rook half-steps of the last run that computed a residual + arg-max (all groups) */
 int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double ms[TTX_K_NKINDS], double bytes[TTX_K_NKINDS]);
 

@@ -18,6 +18,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
+    # TTX_MP_REPEAT=k: the whole job k times in this process under the SAME transport name (a second dtt_dmrgg call of one job)
+    reps = int(os.environ.get("TTX_MP_REPEAT", "1"))
+    rc = 0
+    for _ in range(reps):
+        rc |= one_job()
+    sys.exit(rc)
+
+
+def one_job():
     kind, m, n, r, piv, ng = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
     transport = sys.argv[7] if len(sys.argv) > 7 else "gloo"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -72,8 +81,11 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if os.environ.get("TTX_MP_LEAK") == "1":     # die without closing: the shared-memory segment of this job stays behind under its name
+        sys.stdout.flush()
+        os._exit(1 if bad else 0)
     tt.close()
-    sys.exit(1 if bad else 0)
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":

@@ -307,12 +307,12 @@ def test_rccl_transport_on_real_gpus():
     assert out.stdout.count(" OK") == world
 
 
-def _spawn_ranks(world, argv, extra_env=None, timeout=600):
+def _spawn_ranks(world, argv, extra_env=None, timeout=600, name=None):
     """`world` processes with RANK / WORLD_SIZE (and the TTX_WORLD_* twins the Fortran layer reads), a fresh shm name each."""
     import os
     import subprocess
     import uuid
-    name = "ttx_" + uuid.uuid4().hex[:12]
+    name = name or "ttx_" + uuid.uuid4().hex[:12]
     procs = []
     for rk in range(world):
         env = dict(os.environ, RANK=str(rk), WORLD_SIZE=str(world), TTX_WORLD_RANK=str(rk), TTX_WORLD_SIZE=str(world),
@@ -345,6 +345,46 @@ def test_multi_process_shm_transport(world, args, pipeline):
     outs = _spawn_ranks(world, [sys.executable, os.path.join(root, "tests", "mp_worker.py")] + args.split() + ["shm"], {"TTX_PIPELINE": pipeline})
     for rc, o, e in outs:
         assert rc == 0 and " OK" in o, o[-2000:] + e[-2000:]
+
+
+def test_shm_transport_survives_stale_and_reused_segment_names():
+    """The attach handshake of ttx_comm_init_shm (a nonce per initialisation): (1) a job whose processes die without closing
+    leaves its segment behind under the name -- ready = 1, handshake over --; the next job under the SAME name must not join
+    that segment; (2) two dtt_dmrgg-like jobs in a row inside the same processes reuse the name while rank 0 replaces the
+    segment.  Both must end bit-identical to the oracle (before the handshake the ranks could wait on different barriers)."""
+    import os
+    import sys
+    import uuid
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "ttx_stale_" + uuid.uuid4().hex[:8]
+    cmd = [sys.executable, os.path.join(root, "tests", "mp_worker.py")] + "c 6 33 20 2 4 shm".split()
+    try:
+        for rc, o, e in _spawn_ranks(2, cmd, {"TTX_MP_LEAK": "1"}, name=name):
+            assert rc == 0 and " OK" in o, o[-2000:] + e[-2000:]
+        assert os.path.exists("/dev/shm/" + name), "the leaked segment should still be there"
+        for rc, o, e in _spawn_ranks(2, cmd, name=name):
+            assert rc == 0 and " OK" in o, o[-2000:] + e[-2000:]
+        for rc, o, e in _spawn_ranks(3, [sys.executable, os.path.join(root, "tests", "mp_worker.py")] + "d 8 33 10 2 3 shm".split(), {"TTX_MP_REPEAT": "3"}, name=name):
+            assert rc == 0 and o.count(" OK") == 3, o[-2000:] + e[-2000:]
+    finally:
+        if os.path.exists("/dev/shm/" + name):
+            os.unlink("/dev/shm/" + name)
+
+
+def test_team_halfstep_fault_is_replayed_without_teams(monkeypatch):
+    """k_halfstep_det reports a launch whose grid is smaller than the number of units (never expected: the host sizes the grid
+    from its bound on the ranks) in ctl[3]; ttx_run must see the report after the run -- the finalisation used to clear it --,
+    retire the teams for the engine and repeat the run.  TTX_DE_TEST_FAULT=2 gives the team launches of sweep 2 a grid of one."""
+    monkeypatch.setenv("TTX_DE_TEST_FAULT", "2")
+    monkeypatch.setenv("TTX_DE_TEAM_UNITS", "1000000")
+    s = D.ising_setup("d", 20, 17)
+    tt, oo = _run_both(s, 8, 2)
+    assert tt.det_fallbacks == 1
+    assert np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d])
+    assert [a["val"] for a in tt.sweeps()] == [b["val"] for b in oo["sweeps"]]
+    assert tt.neval == oo["neval"] and tt.quad(s["quad"]) == oo["value"]
+    tt.run()                                   # the engine stays on the wave-per-unit kernel: no second fallback
+    assert tt.det_fallbacks == 1 and tt.quad(s["quad"]) == oo["value"]
 
 
 @pytest.mark.parametrize("world,name", [(2, "ising_C_6_33_20_2_np4"), (4, "ising_C_6_33_20_2_np4"), (2, "ising_C_16_51_32_2_np8")])

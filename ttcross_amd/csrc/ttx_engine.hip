@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -139,6 +140,7 @@ struct ttx_engine {
     int de5_fallbacks = 0;
     int de_slots = 0; size_t lds_de = 0;
     int de_team = 0, de_team_units = 256, det_fallbacks = 0; size_t lds_det = 0;
+    int de_test_fault = 0;              // test hook (TTX_DE_TEST_FAULT=<sweep>): the team half-steps of that sweep get a grid of one unit
     int de_team6_units = 1024; size_t lds_det6 = 0;                                      // ... and by teams of 6 waves, several per CU, for the launches above that   // ... by a team of 14 waves per unit (k_halfstep_det) while the ranks are small
     int lot_rows = 0; size_t lds_der = 0;   // ... four candidates per wave, one per DPP row (k_lottery_eval_de_rows)
     int lot_wave = 0;                       // Ising D/E: lottery candidates and boundary corners by the row-wise wave evaluator (ttx_de.h)
@@ -434,6 +436,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         if (getenv("TTX_DE_TEAM6_UNITS")) h->de_team6_units = atoi(getenv("TTX_DE_TEAM6_UNITS"));
         h->de_team = h->de_v2 && h->lds_det <= 150 * 1024 && !(getenv("TTX_DE_TEAM") && atoi(getenv("TTX_DE_TEAM")) == 0);
         if (getenv("TTX_DE_TEAM_UNITS")) h->de_team_units = atoi(getenv("TTX_DE_TEAM_UNITS"));
+        if (getenv("TTX_DE_TEST_FAULT")) h->de_test_fault = atoi(getenv("TTX_DE_TEST_FAULT"));
         h->lds_de5 = sizeof(double) * de5_lds_doubles(d);
         h->de_v5 = h->de_v2 && de5_fits(d) && h->lds_de5 <= 150 * 1024 && getenv("TTX_DE_V5") && atoi(getenv("TTX_DE_V5")) == 1;
     }
@@ -721,10 +724,19 @@ extern "C" int ttx_comm_init(ttx_engine *h, const uint8_t id[128])
 // shared segment.  Point-to-point: one mailbox per (receiver, side) with a sequence / acknowledge pair; all-reduce: every
 // rank deposits its vector, a sense-reversing barrier, every rank folds the W vectors in rank order (so all ranks get
 // the identical bits), a second barrier before the slots are reused.  Waits are bounded (60 s) and report failure.
+// Attaching is a handshake on a per-initialisation NONCE, so that a rank can never end up on a segment that rank 0 did not
+// create in THIS call (a segment left by a crashed job, or the one of the previous dtt_dmrgg of the same job, still carries
+// ready = 1 and old counters): rank 0 unlinks the name, creates a fresh segment and publishes a random nonce; rank r copies the
+// nonce it sees into hello[r] and waits for go == that nonce, which rank 0 sets once every hello matches.  A segment whose go
+// is already set before the rank said hello is stale by construction; while it waits, a rank re-checks that the NAME still
+// leads to the inode it has mapped (rank 0's unlink + create changes it) and starts over if not.
 struct ShmHeader {
     std::atomic<uint32_t> ready, arrived, sense;
     uint32_t W; uint64_t msz, redcap;
+    std::atomic<uint64_t> nonce, go;
+    std::atomic<uint64_t> hello[256];
 };
+static_assert(sizeof(ShmHeader) <= 4096, "the header shares the first page of the segment");
 struct ShmBox { std::atomic<uint64_t> seq, ack; uint64_t bytes; };
 struct ShmTransport {
     void *base = nullptr; size_t size = 0; std::string name; int rank = 0, W = 1; bool owner = false;
@@ -810,33 +822,78 @@ extern "C" int ttx_comm_init_shm(ttx_engine *h, const char *name)
     T->msz = (h->P.MSZ + 63) & ~(size_t)63;
     T->redcap = std::max<size_t>(std::max(h->QB, h->SB), 8);
     T->size = 4096 + (size_t)T->W * 2 * (64 + T->msz) + (size_t)T->W * T->redcap * sizeof(double);
-    int fd = -1;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     if (T->rank == 0) {
         shm_unlink(T->name.c_str());
-        fd = shm_open(T->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        int fd = shm_open(T->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0 || ftruncate(fd, (off_t)T->size) != 0) { if (fd >= 0) close(fd); delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: cannot create %s", name); }
         T->owner = true;
-    } else {
-        const bool ok = shm_wait([&] {
-            fd = shm_open(T->name.c_str(), O_RDWR, 0600);
-            if (fd < 0) return false;
-            struct stat st;
-            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= T->size) return true;
-            close(fd); fd = -1;
-            return false;
-        });
-        if (!ok) { delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: rank 0 did not create %s", name); }
-    }
-    T->base = mmap(nullptr, T->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (T->base == MAP_FAILED) { T->base = nullptr; delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: mmap failed"); }
-    T->hd = (ShmHeader *)T->base;
-    if (T->rank == 0) {          // a fresh segment is zero-filled: sequence numbers, counters and the sense start at 0
+        T->base = mmap(nullptr, T->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (T->base == MAP_FAILED) { T->base = nullptr; shm_unlink(T->name.c_str()); delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: mmap failed"); }
+        T->hd = (ShmHeader *)T->base;          // a fresh segment is zero-filled: sequence numbers, counters, sense, go and hello start at 0
         T->hd->W = (uint32_t)T->W; T->hd->msz = T->msz; T->hd->redcap = T->redcap;
+        std::random_device rd;
+        uint64_t nonce = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)getpid() << 17) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+        if (nonce == 0) nonce = 1;
+        T->hd->nonce.store(nonce, std::memory_order_relaxed);
         T->hd->ready.store(1u, std::memory_order_release);
+        const bool all = shm_wait([&] {
+            for (int r = 1; r < T->W; r++) if (T->hd->hello[r].load(std::memory_order_acquire) != nonce) return false;
+            return true;
+        });
+        if (!all) { munmap(T->base, T->size); shm_unlink(T->name.c_str()); delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: not all %d ranks attached to %s", T->W, name); }
+        T->hd->go.store(nonce, std::memory_order_release);
     } else {
-        if (!shm_wait([&] { return T->hd->ready.load(std::memory_order_acquire) == 1u; })) { munmap(T->base, T->size); delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: segment never became ready"); }
-        if (T->hd->W != (uint32_t)T->W || T->hd->msz != T->msz || T->hd->redcap != T->redcap) { munmap(T->base, T->size); delete T; return fail(TTX_EINVAL, "ttx_comm_init_shm: the ranks disagree about the problem"); }
+        bool joined = false, mismatch = false;
+        while (!joined && elapsed() < 60.0) {
+            int fd = shm_open(T->name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < T->size) { if (fd >= 0) close(fd); std::this_thread::sleep_for(std::chrono::milliseconds(2)); continue; }
+            const ino_t ino = st.st_ino;
+            void *base = mmap(nullptr, T->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (base == MAP_FAILED) { delete T; return fail(TTX_EHIP, "ttx_comm_init_shm: mmap failed"); }
+            ShmHeader *hd = (ShmHeader *)base;
+            auto still_current = [&] {          // does the name still lead to the segment that is mapped here?
+                int f2 = shm_open(T->name.c_str(), O_RDWR, 0600);
+                struct stat s2;
+                const bool same = f2 >= 0 && fstat(f2, &s2) == 0 && s2.st_ino == ino;
+                if (f2 >= 0) close(f2);
+                return same;
+            };
+            bool restart = false, said = false;
+            uint64_t nonce = 0;
+            auto t_chk = std::chrono::steady_clock::now();
+            while (!restart && elapsed() < 60.0) {
+                if (!said && hd->ready.load(std::memory_order_acquire) == 1u) {
+                    mismatch = hd->W != (uint32_t)T->W || hd->msz != T->msz || hd->redcap != T->redcap;
+                    nonce = hd->nonce.load(std::memory_order_relaxed);
+                    if (mismatch || hd->go.load(std::memory_order_acquire) == nonce) {
+                        // another problem's segment, or one whose initialisation is over: not ours -- wait for rank 0 to replace the name
+                        while (elapsed() < 60.0 && still_current()) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                        restart = true;
+                        break;
+                    }
+                    hd->hello[T->rank].store(nonce, std::memory_order_release);
+                    said = true;
+                }
+                if (said && hd->go.load(std::memory_order_acquire) == nonce) { joined = true; break; }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_chk).count() > 0.02) {
+                    t_chk = std::chrono::steady_clock::now();
+                    if (!still_current()) restart = true;
+                }
+                std::this_thread::yield();
+            }
+            if (joined) { T->base = base; T->hd = hd; }
+            else munmap(base, T->size);
+        }
+        if (!joined) {
+            delete T;
+            return mismatch ? fail(TTX_EINVAL, "ttx_comm_init_shm: the ranks disagree about the problem (or %s belongs to another job)", name)
+                            : fail(TTX_EHIP, "ttx_comm_init_shm: rank 0 did not create %s (or never saw every rank)", name);
+        }
     }
     h->shm = T;
     h->cb.ctx = T; h->cb.sendrecv = shm_sendrecv; h->cb.allreduce = shm_allreduce; h->have_cb = true;
@@ -1236,7 +1293,8 @@ static int run_impl(ttx_engine *h)
                 } else if (FUN == FUN_ISING && h->de_v2) {
                     // while the ranks are small (at most it_ + 1 during sweep it_) a unit gets a team of 14 waves on a CU of its own, up to
                     // 1024 units a team of 6 waves (three such teams fit a CU), beyond that one wave
-                    const int rb = std::min((int)h->RM, it_ + 1), team_slots = rb * ((h->NM + 63) / 64);
+                    const int rb = std::min((int)h->RM, it_ + 1);
+                    const int team_slots = (h->de_test_fault && it_ == h->de_test_fault) ? 1 : rb * ((h->NM + 63) / 64);
                     const bool team = h->de_team && !h->de_v5 && team_slots * G <= h->de_team_units;
                     const bool team6 = h->de_team && !h->de_v5 && !team && team_slots * G <= h->de_team6_units;
                     for (int hh = 0; hh < h->H; hh++) {
@@ -1330,7 +1388,7 @@ static int run_impl(ttx_engine *h)
         if (fin_enqueued) return TTX_OK;
         fin_enqueued = true;
         if (after_val >= 0) HIPCHECK(hipStreamWaitEvent(st, h->ev_val[after_val], 0));
-        HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 4, st));
+        HIPCHECK(hipMemsetAsync(P.ctl, 0, sizeof(int) * 3, st));      // ctl[3] (fault counter of the team / relay half-steps) is read by ttx_run afterwards
         KScope ks(h, TTX_K_OTHER, 2);
         if (nproc > 1) {
             hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
@@ -1447,24 +1505,29 @@ extern "C" int ttx_run(ttx_engine *h)
                 for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
                 rc = run_impl<FUN_ISING>(h);
             }
-            if (!rc && h->de_team && !h->de_v5) {
+            if (h->de_team && !h->de_v5) {
                 // k_halfstep_det found more units than the grid the host sized from its bound on the ranks (never expected):
-                // nothing of the run is kept, the teams are retired for this engine and the run is repeated
+                // nothing of the run is kept -- whatever it returned --, the teams are retired for this engine and the run is repeated.
+                // (ctl[3] is cleared by k_reset at the start of a run only; the finalisation leaves it alone.)
                 int faults = 0;
-                HIPCHECK(hipMemcpy(&faults, h->P.ctl + 3, sizeof(int), hipMemcpyDeviceToHost));
+                (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->qstream);
+                if (hipMemcpy(&faults, h->P.ctl + 3, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) faults = 0;
                 if (faults) {
+                    (void)hipGetLastError();
                     if (h->W > 1) return fail(TTX_EHIP, "ttx_run: k_halfstep_det met a rank above the host's bound; set TTX_DE_TEAM=0");
                     h->de_team = 0; h->det_fallbacks++;
                     for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
                     rc = run_impl<FUN_ISING>(h);
                 }
             }
-            if (!rc && h->de_v5) {
+            if (h->de_v5) {
                 // the relay of k_halfstep_de5 reports a broken hand-over (bounded waits) in ctl[3]: nothing of such a run is
                 // kept, the relay is retired for this engine and the run repeated with k_halfstep_de (identical results)
                 int faults = 0;
-                HIPCHECK(hipMemcpy(&faults, h->P.ctl + 3, sizeof(int), hipMemcpyDeviceToHost));
+                (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->qstream);
+                if (hipMemcpy(&faults, h->P.ctl + 3, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) faults = 0;
                 if (faults) {
+                    (void)hipGetLastError();
                     if (h->W > 1) return fail(TTX_EHIP, "ttx_run: the wave relay of k_halfstep_de5 broke (%d hand-overs); set TTX_DE_V5=0", faults);
                     h->de_v5 = 0; h->de5_fallbacks++;
                     for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
@@ -2201,6 +2264,8 @@ extern "C" int ttx_arith(const ttx_engine *h) { return h ? h->P.arith : -1; }
 extern "C" int ttx_sweep_path(const ttx_engine *h) { return !h ? -1 : h->cluster ? 2 : h->fused ? 1 : 0; }
 extern "C" int64_t ttx_resid_halfsteps(const ttx_engine *h) { return h ? h->n_resid : 0; }
 extern "C" int ttx_cluster_fallbacks(const ttx_engine *h) { return h ? h->cluster_fallbacks : 0; }
+extern "C" int ttx_det_fallbacks(const ttx_engine *h) { return h ? h->det_fallbacks + h->de5_fallbacks : 0; }
+extern "C" int ttx_fun_id(const ttx_engine *h) { return h ? h->cfg.fun_id : -1; }
 extern "C" int ttx_set_profile(ttx_engine *h, int on) { if (!h) return fail(TTX_EINVAL, "null"); h->profile = on != 0; return TTX_OK; }
 extern "C" int ttx_kernel_stats(const ttx_engine *h, int64_t launches[TTX_K_NKINDS], double ms[TTX_K_NKINDS], double bytes[TTX_K_NKINDS])
 {

@@ -333,6 +333,13 @@ class TTCross:
         L.ttx_cluster_fallbacks.argtypes = [c_void_p]
         return int(L.ttx_cluster_fallbacks(self._h))
 
+    @property
+    def det_fallbacks(self):
+        """Runs repeated without the wave teams / relay of the Ising D/E half-step after a reported fault (include/ttx.h)."""
+        L = load_library()
+        L.ttx_det_fallbacks.argtypes = [c_void_p]
+        return int(L.ttx_det_fallbacks(self._h))
+
     def set_profile(self, on=True):
         _check(load_library().ttx_set_profile(self._h, 1 if on else 0))
 

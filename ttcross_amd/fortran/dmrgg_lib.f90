@@ -160,10 +160,19 @@ contains
   type(dtt),intent(in) :: arg
   double precision,intent(out) :: einf,efro,ainf,afro
   double precision,external :: fun
-  double precision,intent(inout),optional :: par(*)
+  double precision,intent(inout),optional,target :: par(*)
   integer,intent(out),optional :: pivot(tt_size)
   integer(c_int32_t) :: pv(tt_size)
   if(.not.c_associated(arg%ttx))then;write(*,*)'dtt_accchk: tensor train is not resident on the device (call dtt_dmrgg first)';stop;endif
+  ! a host-evaluated integrand is checked against the fun / par given HERE, as in the reference (:1081-1166); the pointers that
+  ! dtt_dmrgg registered may belong to a temporary or to storage the caller has released since
+  if(ttx_fun_id(arg%ttx).eq.TTX_FUN_HOST)then
+   if(present(par))then
+    call ttx_check(ttx_set_integrand_host(arg%ttx,c_funloc(fun),c_loc(par)),'dtt_accchk')
+   else
+    call ttx_check(ttx_set_integrand_host(arg%ttx,c_funloc(fun),c_null_ptr),'dtt_accchk')
+   end if
+  end if
   call ttx_check(ttx_accchk(arg%ttx,int(nlot,c_int32_t),einf,efro,ainf,afro,pv),'dtt_accchk')
   if(present(pivot))pivot(1:arg%m)=pv(1:arg%m)
  end subroutine
@@ -279,7 +288,9 @@ contains
   character(kind=c_char) :: cnam(257)
   integer :: stat,i
   call get_environment_variable('TTX_SHM_NAME',nam,status=stat)
-  if(stat.ne.0)nam='ttx_job'
+  if(stat.ne.0)then       ! default: one name per launcher (the ranks of a job share their parent process), not one for the whole node
+   write(nam,'(a,i0)')'ttx_job_',ttx_getppid()
+  end if
   do i=1,len_trim(nam); cnam(i)=nam(i:i); end do
   cnam(len_trim(nam)+1)=c_null_char
   rc=ttx_comm_init_shm(h,cnam)
@@ -291,26 +302,39 @@ contains
   type(c_ptr),value :: h
   integer(c_int8_t),target :: id(128)
   character(len=512) :: fnam
-  integer :: stat,wrank,wsize,u,tries,ios
+  character(len=540) :: fnam2
+  integer :: stat,wrank,wsize,u,tries,ios,fsz
+  integer,save :: comm_seq=0
   logical :: there
   call ttx_world(wrank,wsize)
   call get_environment_variable('TTX_COMM_FILE',fnam,status=stat)
   if(stat.ne.0)then;write(*,*)'dtt_dmrgg: TTX_WORLD_SIZE > 1 needs TTX_COMM_FILE (a path all ranks can reach)';stop;endif
+  ! One id file per initialisation: the name carries a sequence number that every rank counts the same way (one per dtt_dmrgg
+  ! call of the job), so a later call never reads the id of an earlier one; rank 0 removes what a crashed job may have left
+  ! under the name before it writes, and removes its own file once every rank has joined (ttx_comm_init returns).
+  comm_seq=comm_seq+1
+  write(fnam2,'(a,a,i0)')trim(fnam),'.',comm_seq
   if(wrank.eq.0)then
+   open(newunit=u,file=trim(fnam2),status='old',iostat=ios); if(ios.eq.0)close(u,status='delete')
    rc=ttx_comm_unique_id(id); if(rc.ne.0)return
-   open(newunit=u,file=trim(fnam)//'.tmp',access='stream',form='unformatted',status='replace')
+   open(newunit=u,file=trim(fnam2)//'.tmp',access='stream',form='unformatted',status='replace')
    write(u)id; close(u)
-   call rename(trim(fnam)//'.tmp',trim(fnam))
+   call rename(trim(fnam2)//'.tmp',trim(fnam2))
   else
-   do tries=1,600
-    inquire(file=trim(fnam),exist=there)
-    if(there)exit
-    call sleep(1)
+   do tries=1,6000
+    inquire(file=trim(fnam2),exist=there,size=fsz)
+    if(there.and.fsz.eq.128)exit
+    ios=ttx_usleep(100000_c_int32_t)
    end do
-   if(.not.there)then;write(*,*)'dtt_dmrgg: no unique id in ',trim(fnam);stop;endif
-   open(newunit=u,file=trim(fnam),access='stream',form='unformatted',status='old',iostat=ios)
-   read(u)id; close(u)
+   if(.not.(there.and.fsz.eq.128))then;write(*,*)'dtt_dmrgg: no unique id in ',trim(fnam2);stop;endif
+   open(newunit=u,file=trim(fnam2),access='stream',form='unformatted',status='old',iostat=ios)
+   if(ios.ne.0)then;write(*,*)'dtt_dmrgg: cannot open ',trim(fnam2);stop;endif
+   read(u,iostat=ios)id; close(u)
+   if(ios.ne.0)then;write(*,*)'dtt_dmrgg: short read of the unique id in ',trim(fnam2);stop;endif
   end if
   rc=ttx_comm_init(h,id)
+  if(wrank.eq.0)then
+   open(newunit=u,file=trim(fnam2),status='old',iostat=ios); if(ios.eq.0)close(u,status='delete')
+  end if
  end function
 end module

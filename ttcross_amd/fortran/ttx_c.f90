@@ -39,6 +39,15 @@ module ttx_c
   function ttx_set_integrand_host(h,fun,par) bind(C,name='ttx_set_integrand_host') result(rc)   ! the user's `fun`, lib/dmrgg.f90:18
    import; type(c_ptr),value :: h; type(c_funptr),value :: fun; type(c_ptr),value :: par; integer(c_int) :: rc
   end function
+  function ttx_getppid() bind(C,name='getppid') result(p)      ! libc: the launcher's pid, shared by the ranks of a job
+   import; integer(c_int) :: p
+  end function
+  function ttx_usleep(us) bind(C,name='usleep') result(rc)
+   import; integer(c_int32_t),value :: us; integer(c_int) :: rc
+  end function
+  function ttx_fun_id(h) bind(C,name='ttx_fun_id') result(id)
+   import; type(c_ptr),value :: h; integer(c_int) :: id
+  end function
   function ttx_host_calls(h) bind(C,name='ttx_host_calls') result(n)
    import; type(c_ptr),value :: h; integer(c_int64_t) :: n
   end function
