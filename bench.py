@@ -6,7 +6,7 @@ on the workload BASELINE.json's metric is quoted on: Ising C_64, n=51, maxrank 3
 `value` = neval / wall(dtt_dmrgg), the reference's own figure of merit (test_crs_ising.f90:146-156), with all
 inputs resident in HBM.  For N>1 the SAME problem is split over N GPUs by bond groups (strong scaling).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c64|c16|d32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c64|c16|d32|d256|mvn128|ort|svd...] [--arith exact|fast]
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (the rook half-step:
 fiber evaluation + residual + arg-max), `cpu_baseline` = the genuine reference (oracle/_ref, kind
@@ -213,6 +213,31 @@ def bench_utility(a, D, E):
                          "unit": "GB/s", "frac": passes * 8.0 * sz / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_step": passes * 8.0 * sz, "householder_flops_per_step": flops,
                          "note": "63 dependent per-core stages of < 0.5 MB each: launch- and latency-bound, see DESIGN.md section 8"}}
+    if not a.no_cpu_baseline:
+        # cpu_baseline: the GENUINE reference's dtt_ort / dtt_svd (LAPACK through MKL sequential, as the reference links it) on the
+        # IDENTICAL train -- written here with ttx_write in the reference's stream format, read there with its own dtt_read --
+        # by oracle/_ref/ref_tt_timing (our own small timing driver around the reference's modules; bench infrastructure)
+        exe = os.path.join(ROOT, "oracle", "_ref", "ref_tt_timing")
+        if os.path.exists(exe):
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                fn = os.path.join(td, "train.tt")
+                t = E.TTCross.from_cores(cores)
+                t.write(fn)
+                t.close()
+                env = dict(os.environ, OMP_NUM_THREADS="1", MKL_THREADING_LAYER="SEQUENTIAL")
+                try:
+                    o = subprocess.run([exe, fn, op, "1e-10", "12"], capture_output=True, text=True, env=env, timeout=300).stdout
+                    mm = re.search(r"calls\s+(\d+)\s+median_ms\s+([0-9.]+)\s+ranks_max\s+(\d+)", o)
+                    if mm:
+                        cms = float(mm.group(2))
+                        line["cpu_baseline"] = {"value": src.d / (cms * 1e-3), "unit": "cores/s", "cores": 1, "kind": "reference", "ms_per_step": cms,
+                                                "ranks_out_max": int(mm.group(3)),
+                                                "sample": f"{mm.group(1)} calls of the genuine reference's {'dtt_ort' if op == 'ort' else 'dtt_svd(tol=1e-10)'} (lib/tt.f90, LAPACK via MKL sequential, "
+                                                          "1 thread) on the identical train, read with its own dtt_read; median time per call"}
+                        line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+                except Exception as e:  # noqa: BLE001
+                    print(f"cpu_baseline (tt_lib): {type(e).__name__}: {e}", file=sys.stderr)
     print(json.dumps(line))
 
 
@@ -297,6 +322,43 @@ def supervise(a, rank, world):
     return 1
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher: this process, which has not touched the GPU and never will, starts
+    the N ranks itself as FRESH child processes (never a re-exec) with the environment torch.distributed.run would give them
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), relays rank 0's result line and returns the
+    worst exit code.  Each rank then supervises its measurement as under the launcher (supervise())."""
+    import signal
+    port = _free_port()
+    procs = []
+    for rk in range(a.gpus):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rk == 0 else subprocess.DEVNULL, text=True, start_new_session=True))
+    deadline = time.time() + 2 * a.attempt_timeout + 120
+    rc = 0
+    out0 = ""
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        for p in procs[1:]:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        rc = 1
+        print("[bench] the ranks did not finish in time; stopping them", file=sys.stderr, flush=True)
+    for p in procs:
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)            # exactly the process groups started above
+            except ProcessLookupError:
+                pass
+            p.wait()
+        rc = max(rc, abs(p.returncode or 0))
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            print(ln, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +368,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the k2_streaming and single_group side measurements (profiler runs: only the workload's own launches)")
     ap.add_argument("--groups", type=int, default=0, help="bond groups = MPI ranks of the reference's domain split; default 8 (config 3 of BASELINE.json) at every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arith", default="exact", choices=["exact", "fast"], help="TTX_ARITH: exact (default; every fp64 operation of the integrand in the reference's order) "
+                    "or fast (Ising D/E, mvn: re-associated O(d) evaluation, tolerance-checked)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (gloo: rehearsal with several ranks on one GPU)")
     ap.add_argument("--attempt-timeout", type=float, default=420.0, help="N>1: seconds one transport attempt may take before the supervisors stop it")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)        # set by supervise(): this process does the measurement
@@ -315,9 +379,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if a.gpus != world and world == 1 and a.gpus > 1 and a.workload not in UTIL_WORKLOADS:
+        raise SystemExit(self_launch(a))       # no launcher: start the ranks here (fresh children; this process stays off the GPU)
     if world > 1 and not a.child and a.workload not in UTIL_WORKLOADS:
         raise SystemExit(supervise(a, rank, world))
     if a.child and os.environ.get("TTX_BENCH_TEST_FAULT"):       # tests/test_dist_cpu.py: "<attempt>:<rank>:hang|crash|dry"
@@ -362,9 +425,9 @@ def main():
     s = D.ising_setup(argv[1], argv[2], argv[3]) if argv[0] == "ising" else D.box_setup(argv[0], argv[2], argv[3])
     groups = a.groups or max(4 if a.workload == "mvn128" else 8, world)
     tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
-                   nproc=groups, device=local, world_rank=rank, world_size=world) if world > 1 else \
+                   nproc=groups, device=local, world_rank=rank, world_size=world, arith=a.arith) if world > 1 else \
         E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
-                  nproc=groups, device=local)
+                  nproc=groups, device=local, arith=a.arith)
     transport = "none (single process)"
     if world > 1:
         # data path between GPUs: in-library RCCL point-to-point / all-reduce on the engine's stream; if RCCL cannot
@@ -385,7 +448,7 @@ def main():
         else:
             tt.close()
             tt = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
-                           nproc=groups, device=local, world_rank=rank, world_size=world)
+                           nproc=groups, device=local, world_rank=rank, world_size=world, arith=a.arith)
             if a.backend == "nccl" and gloo_pg is None:
                 raise SystemExit("neither the RCCL transport nor a gloo fallback group is available")
             tt.set_dist_transport(dist, group=gloo_pg)
@@ -420,7 +483,7 @@ def main():
     if world > 1 and rank == 0:
         try:
             t1 = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
-                           nproc=groups, device=local)
+                           nproc=groups, device=local, arith=a.arith)
             t1.run()
             v1 = t1.quad(s["quad"])
             multi_check = "integral identical to the single-process run of the same bond groups" if (v1 == value and t1.neval == tt.neval) else \
@@ -456,7 +519,7 @@ def main():
               "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS}
         if groups != 1:
             t1 = E.TTCross(s["n"], s["fun_id"], s["par"], argv[4], pivoting=argv[5], accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s["aux"],
-                           nproc=1, device=local)
+                           nproc=1, device=local, arith=a.arith)
             t1.run()
             tb = time.perf_counter()
             for _ in range(3):
@@ -468,29 +531,42 @@ def main():
     if rank != 0:
         return
     path = tt.sweep_path()
-    # the chain path's half-step kernel by integrand: the wave-per-pivot kernels of Ising D/E and mvn, the generic one otherwise
-    chain_k = "k_halfstep_de / k_halfstep_det" if (argv[0] == "ising" and argv[1] in ("d", "e")) else "k_halfstep_mvn" if argv[0] == "mvn" else "k_halfstep"
+    arith = tt.arith
+    heavy = (argv[0] == "ising" and argv[1] in ("d", "e")) or argv[0] == "mvn"
+    # the chain path's half-step kernel by integrand and arithmetic: the wave-per-pivot kernels of Ising D/E and mvn (exact), the generic
+    # kernel with the table evaluators of ttx_fast.h (fast), the generic kernel otherwise
+    chain_k = "k_halfstep" if (arith == "fast" and heavy) else "k_halfstep_de / k_halfstep_det" if (argv[0] == "ising" and argv[1] in ("d", "e")) else \
+              "k_halfstep_mvn" if argv[0] == "mvn" else "k_halfstep"
     kname = {"chain": chain_k, "fused": "k_sweep_fused", "cluster": "k_sweep_cluster"}[path]
-    kdesc = {"chain": chain_k + " (one rook half-step: fiber evaluation + residual + arg-max)",
+    kdesc = {"chain": chain_k + (" with the table evaluators of TTX_ARITH=fast (one rook half-step: O(d) fiber evaluation + residual K2 + arg-max)" if (arith == "fast" and heavy)
+                                 else " (one rook half-step: fiber evaluation + residual + arg-max)"),
              "fused": "k_sweep_fused (whole sweep of a bond group in one workgroup; bytes = its rook half-steps)",
              "cluster": "k_sweep_cluster (whole sweep of a bond group by a cluster of workgroups; bytes = its rook half-steps)"}[path]
+    # HBM traffic of that kernel per launch: FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 --pmc passes of THIS command and THIS
+    # round's kernels (profiles/measure_r03.sh writes profiles/r03_pmc_fetch_write_<workload>_<arith>_g<groups>.csv); the file's git blob id
+    # is recorded so that the number can be traced to the committed measurement.  Absent file: null.
     traffic = None
     traffic_source = None
-    try:   # per-launch FETCH_SIZE + WRITE_SIZE of that kernel from the committed PMC passes of this same command
+    try:
         import csv
-        f = w = None
-        for row in csv.reader(l for l in open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_c64_g8.csv")) if not l.startswith("#")):
-            if len(row) >= 6 and kname in row[1]:
-                if row[2] == "FETCH_SIZE":
-                    f = float(row[5])
-                if row[2] == "WRITE_SIZE":
-                    w = float(row[5])
-        if f is not None and w is not None and a.workload == "c64" and groups == 8 and path == "cluster":
-            traffic = (f + w) * 1024.0
-            traffic_source = ("profiles/r01_pmc_fetch_write_c64_g8.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command recorded in round 1 "
-                              "(NOT measured in this run; the kernel's data flow is unchanged since)")
+        pm = os.path.join(ROOT, "profiles", f"r03_pmc_fetch_write_{a.workload}_{arith}_g{groups}.csv")
+        if os.path.exists(pm) and world == 1:
+            f = w = None
+            first = kname.split(" ")[0]
+            for row in csv.reader(l for l in open(pm) if not l.startswith("#")):
+                if len(row) >= 6 and row[1].startswith(first):
+                    if row[2] == "FETCH_SIZE" and f is None:
+                        f = float(row[5])
+                    if row[2] == "WRITE_SIZE" and w is None:
+                        w = float(row[5])
+            if f is not None and w is not None:
+                traffic = (f + w) * 1024.0
+                blob = subprocess.run(["git", "hash-object", pm], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+                traffic_source = (f"{os.path.relpath(pm, ROOT)} (git blob {blob[:12] or 'n/a'}): mean FETCH_SIZE + WRITE_SIZE per launch of {first}, separate rocprofv3 --pmc "
+                                  "passes of this command with this round's kernels (not collected in this run)")
     except Exception:  # noqa: BLE001
         traffic = None
+    hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     out = {
         "metric": "fiber evals/s (neval / wall time of dtt_dmrgg), " + desc,
         "value": neval / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -498,19 +574,35 @@ def main():
         "dtype": "f64", "data": "synthetic (integrand evaluated on the fly; Gauss-Legendre nodes/weights; flang-compatible lottery RNG stream)",
         "multi_gpu_check": multi_check,
         "config": {"workload": desc, "driver": ("test_crs_ising " + " ".join(str(x) for x in argv[1:])) if argv[0] == "ising" else ("test_crs_mvn " + " ".join(str(x) for x in argv[2:])), "bond_groups": groups, "transport": transport,
+                   "arith": arith, "sweep_path": path,
                    "neval_per_step": neval // a.steps, "sweeps": nsweeps, "integral": value,
                    "rel_err_vs_analytic": abs(1 - value / s["tru"]) if s["tru"] else None},
-        "roofline": {"kernel": kdesc, "bound": "hbm", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "avg_launch_us": avg_us, "launches_per_step": hs["launches"] / max(1, min(a.steps, 3)),
-                     "algorithmic_bytes_per_launch": bytes_per_launch},
+        # `bound` names what limits the dominant kernel on THIS path: "hbm" where the half-step is its residual sweep K2 (fast mode of
+        # the heavy integrands, generic chain), "fp64-valu" where it is the integrand's dependent fp64 chain (exact Ising D/E, mvn),
+        # "latency" for the whole-sweep kernels (a launch moves ~4 MB in ~300 us: achieved / peak are then the measured launch time and
+        # the modelled floor of its dependent chain, filled in below; the HBM view stays in `hbm`)
+        "roofline": dict({"kernel": kdesc, "bound": "hbm"}, **hbm, traffic=traffic, traffic_source=traffic_source,
+                         avg_launch_us=avg_us, launches_per_step=hs["launches"] / max(1, min(a.steps, 3)),
+                         algorithmic_bytes_per_launch=bytes_per_launch),
         "kernel_ms_per_step": {k: v["ms"] / max(1, min(a.steps, 3)) for k, v in agg.items()},
     }
     # K1 (fiber evaluation) as fp64 vector work, SURVEY 8(d): algorithmic flops per evaluation of the integrand
     dd = len(s["n"])
     fl = (5 * dd + 1) if argv[1] == "c" else (2 * dd * dd + dd + 20) if argv[0] == "mvn" else (6 * dd * (dd + 1) // 2 + 5 * dd)
-    out["k1_evaluation"] = {"flops_per_eval": fl, "achieved": (neval / dt) * fl / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": (neval / dt) * fl / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
+    runs_p = max(1, min(a.steps, 3))
+    k1_ms = (agg["halfstep"]["ms"] + agg["lottery"]["ms"]) / runs_p            # the kernels that evaluate (profile pass)
+    if arith == "fast" and heavy:
+        out["k1_evaluation"] = {"flops_per_eval_reference_formula": fl, "note": "TTX_ARITH=fast does not execute the reference's O(d^2) formula: per fiber element it multiplies the "
+                                "~18 x 18 (after the 2^-54 cut, triangular) range factors through the free dimension, everything else comes from per-pivot tables (ttx_fast.h); "
+                                "the evaluation is a few microseconds per half-step and the half-step is bound by its residual sweep (roofline.bound = hbm)"}
+    else:
+        out["k1_evaluation"] = {"flops_per_eval": fl, "achieved": (neval / dt) * fl / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": (neval / dt) * fl / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
+        if heavy and path == "chain" and k1_ms > 0:       # exact Ising D/E / mvn: the half-step IS the integrand's fp64 chain
+            ach = (neval / a.steps) * fl / (k1_ms * 1e-3) / 1e12
+            out["roofline"].update({"bound": "fp64-valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS,
+                                    "hbm": hbm, "note": "algorithmic flops of the reference's formula per evaluation x evaluations per step / time of the evaluating kernels "
+                                                        "(lottery + half-steps, HIP events); every product / sum kept in the reference's order"})
     # The HBM roofline is the wrong yardstick for the sweep kernel at BASELINE sizes (a launch moves 3.8 MB in ~300 us): what
     # bounds it is a chain of DEPENDENT operations.  Latency model of one launch, from unit costs measured in this run on
     # one wave (ttx_k_latency_probe) and the operation counts of the algorithm:
@@ -540,6 +632,9 @@ def main():
                 "modelled_floor_us_per_launch": model_us, "measured_us_per_launch": avg_us, "frac_of_floor": model_us / avg_us if avg_us else None,
                 "note": "floor = bond steps x (lottery + half-steps + append), each = dependent fp64 chain of one evaluation + residual + "
                         "2 L2 round trips + 12 LDS reads at the unit latencies measured on this device in this run"}
+            if path in ("cluster", "fused") and avg_us > 0:
+                out["roofline"].update({"bound": "latency", "achieved": avg_us, "peak": model_us, "unit": "us per launch (peak = modelled floor of the dependent chain; lower is better)",
+                                        "frac": model_us / avg_us, "hbm": hbm})
         except Exception as e:  # noqa: BLE001
             out["latency_model"] = {"error": str(e)}
     if k2:

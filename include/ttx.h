@@ -236,6 +236,11 @@ int ttx_exp_host(int64_t n, const double *x, double *out);
  * per fp64 IEEE division in a dependent chain [4], each measured on one wave */
 int ttx_k_latency_probe(int32_t device, double out[5]);
 
+/* RCCL loop-back self-test on one device (pools without a second GPU): a one-rank communicator, a grouped ncclSend / ncclRecv of
+ * a msg_bytes message to itself, the MAX all-reduce of 4 doubles and a SUM all-reduce of nsum doubles, all on a non-blocking
+ * stream as in the multi-GPU data path (ttx_comm_init, lib/dmrgg.f90:763-958 replaced); TTX_OK when every byte came back */
+int ttx_k_rccl_selftest(int32_t device, int64_t msg_bytes, int32_t nsum);
+
 /* placement probe: the XCD (XCC_ID hardware register) on which each of `nblocks` workgroups of a plain 1-D launch
  * ran; the cluster sweep kernel relies on workgroups being dealt round-robin to the 8 XCDs */
 int ttx_k_xcc_map(int32_t device, int32_t nblocks, int32_t *out);

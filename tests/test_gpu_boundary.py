@@ -81,6 +81,31 @@ def test_nan_integrand_neither_faults_nor_hangs(userfun, name, piv, nproc):
     tt.close()
 
 
+NAN_CASES = [("c_node", 2, 1, {}), ("c_node", 2, 3, {}), ("c_node", 1, 2, {"TTX_SWEEP": "fused"}), ("c_node", 2, 2, {"TTX_SWEEP": "chain"}),
+             ("c_node", 0, 1, {}), ("d_node", 2, 1, {}), ("d_node", 3, 2, {}), ("e_node", 1, 1, {"TTX_DE_TEAM_UNITS": "1000000"}),
+             ("d_weight", 2, 1, {}), ("d_weight", 2, 2, {"TTX_DE_TEAM_UNITS": "1000000"}), ("d_weight", 1, 1, {"TTX_DE_TEAM_UNITS": "0", "TTX_DE_TEAM6_UNITS": "1000000"}),
+             ("d_weight", 2, 1, {"TTX_DE_TEAM": "0"}), ("d_weight_fast", 2, 2, {}), ("d_weight_fast", 0, 1, {}), ("d_node", -1, 1, {}),
+             ("mvn_inf", 2, 1, {}), ("mvn_inf", 1, 2, {}), ("mvn_inf_fast", 2, 2, {}), ("mvn_inf", -1, 1, {})]
+
+
+@pytest.mark.parametrize("case,piv,nproc,env", NAN_CASES, ids=[f"{c[0]}_p{c[1]}_g{c[2]}" + "".join("_" + v for v in c[3].values()) for c in NAN_CASES])
+def test_nan_through_builtin_device_integrands(case, piv, nproc, env):
+    """NaN / Inf through the BUILT-IN integrands (the host-callback test above drives only the generic chain kernels): a NaN node
+    or weight of the Ising integrands on the cluster, fused and chain paths and through the D/E division kernels (wave per unit,
+    14- and 6-wave teams, lane per element), an infinite entry of the mvn inverse covariance, the table evaluators of
+    TTX_ARITH=fast.  Every arg-max falls back to the first position when nothing compares (idamax), so every pivot must stay in
+    range and the run must end.  One process per case: a GPU memory fault (the round-2 finding) fails the case, not the runner."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "nan_worker.py"), case, str(piv), str(nproc)], capture_output=True, text=True, env=e, timeout=300)
+    blob = p.stdout + p.stderr
+    assert "Memory access fault" not in blob and "core dump" not in blob.lower(), blob[-3000:]
+    assert p.returncode == 0 and " OK" in p.stdout, blob[-3000:]
+
+
 def test_mvn_normalisation_that_underflows_is_refused():
     """det of the covariance underflows to 0 at d = 300 (0.08^300): sqrt((2 pi)^d det) = 0 would make every value inf/NaN."""
     import oracle_lib as O

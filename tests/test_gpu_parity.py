@@ -307,6 +307,18 @@ def test_rccl_transport_on_real_gpus():
     assert out.stdout.count(" OK") == world
 
 
+def test_rccl_loopback_selftest():
+    """The RCCL transport's primitives on the one GPU of this pool: a one-rank communicator, a grouped ncclSend / ncclRecv of a
+    neighbour-sized message to itself, the MAX and SUM all-reduces of the sweep, on a non-blocking stream (include/ttx.h:
+    ttx_k_rccl_selftest).  The 2-GPU test above cannot run here; this one at least moves bytes through librccl."""
+    import ctypes
+    L = E.load_library()
+    L.ttx_k_rccl_selftest.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]
+    for nbytes, nsum in [(8 * (64 * 101 + 64 * 64) + 1040, 8 * 64 * 64 + 16), (4096, 3), (1, 1)]:
+        rc = L.ttx_k_rccl_selftest(0, nbytes, nsum)
+        assert rc == 0, L.ttx_last_error().decode()
+
+
 def _spawn_ranks(world, argv, extra_env=None, timeout=600, name=None):
     """`world` processes with RANK / WORLD_SIZE (and the TTX_WORLD_* twins the Fortran layer reads), a fresh shm name each."""
     import os

@@ -718,6 +718,60 @@ extern "C" int ttx_comm_init(ttx_engine *h, const uint8_t id[128])
     NCCLCHECK(g_rccl.CommInitRank(&h->comm, h->W, u, h->wrank));
     return TTX_OK;
 }
+// Loop-back self-test of the RCCL transport on ONE device: a communicator of one rank, then exactly the calls the multi-GPU data
+// path makes -- a grouped ncclSend / ncclRecv pair of one packed neighbour message (ncclChar) on a non-blocking stream, the
+// 3-double MAX all-reduce of the sweep maxima and a SUM all-reduce of doubles (quadrature partials / per-sweep summary) -- each
+// followed by a byte comparison.  It exercises the dlopen'ed symbol table, the datatypes and the stream ordering on pools where
+// a second GPU (and with it ttx_comm_init with world_size > 1) is not available.
+extern "C" int ttx_k_rccl_selftest(int32_t device, int64_t msg_bytes, int32_t nsum)
+{
+    if (msg_bytes < 1 || nsum < 1) return fail(TTX_EINVAL, "ttx_k_rccl_selftest: bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TTX_ENODEV, "no HIP device");
+    HIPCHECK(hipSetDevice(device));
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId u;
+    NCCLCHECK(g_rccl.GetUniqueId(&u));
+    ncclComm_t comm = nullptr;
+    NCCLCHECK(g_rccl.CommInitRank(&comm, 1, u, 0));
+    hipStream_t st = nullptr;
+    char *dsend = nullptr, *drecv = nullptr; double *dred = nullptr, *dout = nullptr;
+    std::vector<char> hs((size_t)msg_bytes), hr((size_t)msg_bytes);
+    std::vector<double> hd((size_t)nsum + 4), ho((size_t)nsum + 4);
+    for (int64_t i = 0; i < msg_bytes; i++) hs[(size_t)i] = (char)((i * 131 + 7) & 0xff);
+    for (size_t i = 0; i < hd.size(); i++) hd[i] = 1.0 / (double)(i + 3) - 0.25 * (double)(i % 5);
+    int bad = 0;
+    auto body = [&]() -> int {
+        HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHECK(hipMalloc((void **)&dsend, (size_t)msg_bytes)); HIPCHECK(hipMalloc((void **)&drecv, (size_t)msg_bytes));
+        HIPCHECK(hipMalloc((void **)&dred, sizeof(double) * hd.size())); HIPCHECK(hipMalloc((void **)&dout, sizeof(double) * hd.size()));
+        HIPCHECK(hipMemcpyAsync(dsend, hs.data(), (size_t)msg_bytes, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemsetAsync(drecv, 0, (size_t)msg_bytes, st));
+        HIPCHECK(hipMemcpyAsync(dred, hd.data(), sizeof(double) * hd.size(), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemsetAsync(dout, 0, sizeof(double) * hd.size(), st));
+        NCCLCHECK(g_rccl.GroupStart());
+        NCCLCHECK(g_rccl.Send(dsend, (size_t)msg_bytes, ncclChar, 0, comm, st));
+        NCCLCHECK(g_rccl.Recv(drecv, (size_t)msg_bytes, ncclChar, 0, comm, st));
+        NCCLCHECK(g_rccl.GroupEnd());
+        NCCLCHECK(g_rccl.AllReduce(dred, dout, 4, ncclDouble, ncclMax, comm, st));                          // amax, pivotmax, -pivotmin (+ pad)
+        NCCLCHECK(g_rccl.AllReduce(dred + 4, dout + 4, (size_t)nsum, ncclDouble, ncclSum, comm, st));        // summary / quadrature partials
+        HIPCHECK(hipMemcpyAsync(hr.data(), drecv, (size_t)msg_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(ho.data(), dout, sizeof(double) * ho.size(), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        if (memcmp(hs.data(), hr.data(), (size_t)msg_bytes) != 0) bad |= 1;
+        if (memcmp(hd.data(), ho.data(), sizeof(double) * hd.size()) != 0) bad |= 2;
+        return TTX_OK;
+    };
+    rc = body();
+    if (dsend) (void)hipFree(dsend); if (drecv) (void)hipFree(drecv); if (dred) (void)hipFree(dred); if (dout) (void)hipFree(dout);
+    if (st) (void)hipStreamDestroy(st);
+    (void)g_rccl.CommDestroy(comm);
+    if (rc) return rc;
+    if (bad) return fail(TTX_EHIP, "ttx_k_rccl_selftest: %s came back different", bad == 1 ? "the point-to-point message" : bad == 2 ? "an all-reduce" : "message and all-reduce");
+    return TTX_OK;
+}
+
 // ---- built-in node-local host transport over POSIX shared memory ------------------------------------------------
 // For jobs whose processes share a node but cannot use RCCL (several ranks on ONE GPU -- RCCL refuses that -- or no
 // librccl), and for launchers without MPI (the Fortran drop-in layer): the ttx_transport primitives implemented on a
