@@ -26,8 +26,16 @@
 // first-max rule is applied on global fiber positions, reused partial results are bit-identical by construction.
 #pragma once
 #include "ttx_fused.h"
+#include "ttx_mvn.h"       // mvn_lane: one double of a wave by v_readlane
 
 #define CB 256      // threads of a cluster workgroup
+#ifndef TTX_CL_CF
+#define TTX_CL_CF 0    // factor entries of the residual requested before the evaluation (measured: 16 -> +1.4 % run time, registers)
+#endif
+#define F_ISING_CL f_ising_c4p
+#ifndef TTX_CL_UNR
+#define TTX_CL_UNR 16   // factor loads of the residual in flight per batch (8: +0.6 % run time, 32: no further gain)
+#endif
 
 // Ising C integrand from VALUE rows, with the two running sums resumed from per-row prefix states: (pv, pvk) is the
 // state of the descending sum after the right row bn (dims A+3..m), (pw, pwk) the state of the ascending sum after
@@ -41,24 +49,56 @@ __device__ __forceinline__ double f_ising_c4p(int m, int A, const double *an, co
     double v = pv, w = pw, vk = pvk, wk = pwk;
     auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
     auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
+#ifndef TTX_CL_PIPE
+#define TTX_CL_PIPE 0      // 1: chain8p (LDS reads one chunk ahead of the dependent steps; measured 4 % slower: registers), 0: chain8v
+#endif
+#if TTX_CL_PIPE
+#define CHAIN8 chain8p
+#else
+#define CHAIN8 chain8v
+#endif
     vstep(s2n); vstep(s1n);
-    chain8v<true>(an, A, vstep);
+    CHAIN8<true>(an, A, vstep);
     wstep(s1n); wstep(s2n);
-    chain8v<false>(bn, nb, wstep);
+    CHAIN8<false>(bn, nb, wstep);
     double b = 1.0 / (v * w);
     double f = 2 * b;
     auto fstep = [&](double xv) { f = f * xv; };
-    chain8v<false>(aw, A, fstep);
+    CHAIN8<false>(aw, A, fstep);
     fstep(s1w); fstep(s2w);
-    chain8v<false>(bw, nb, fstep);
+    CHAIN8<false>(bw, nb, fstep);
     return f;
+}
+
+// arg-max over a wave by the first-max rule (larger |.| wins, ties go to the lower position) in two cheap passes on the DPP
+// path: the maximum of |.| (an fp64 max per step), then the smallest (position, sign) key among the lanes that hold it (an
+// integer min per step) -- a third of the instructions of the three-operand compare-and-select of wave_argmax.  a is never NaN
+// (a NaN residual never replaces the start value -1), so fmax and == are exact here.  Result in every lane.
+__device__ __forceinline__ int wave_min_i(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0xb1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x4e, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x124, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x128, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ void wave_argmax2(double &a, double &v, int &idx)
+{
+    const double amx = wave_max(a);
+    const int key = (a == amx && idx != INT_MAX) ? ((idx << 1) | (signbit(v) ? 1 : 0)) : INT_MAX;
+    const int kmin = wave_min_i(key);
+    a = amx;
+    if (kmin == INT_MAX) { idx = INT_MAX; v = 0.0; }
+    else { idx = kmin >> 1; v = (kmin & 1) ? -amx : amx; }
 }
 
 // 16-byte records exchanged between the blocks of a cluster: one store / one load instruction each, agent scope
 // (sc1: the store goes through to the point of coherence, the load does not hit in the vector L1)
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 struct ClRec { u4 a, b; };
-static_assert(sizeof(ClRec) == sizeof(ClPart), "record buffers are sized as ClPart");
+static_assert(sizeof(ClRec) == sizeof(ClPart), "record buffers are sized as ClPart: [2][G][TTX_CLREC] u4 arg-max records, then as many running-maximum records");
 __device__ __forceinline__ void st16(void *p, u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ u4 ld16(const void *p)
 {
@@ -100,7 +140,10 @@ __device__ __forceinline__ bool cluster_sync(unsigned *ctr, unsigned target, int
 #define CST_DECL const bool t_me = (threadIdx.x == 0 && g == 0 && cb == 0); long long t_prev = wall_clock64()
 #define CST(k) do { if (t_me) { long long t_now = wall_clock64(); gs.stamp[0][k] += t_now - t_prev; t_prev = t_now; } } while (0)
 #define CST_END() do { if (t_me) gs.nstamp[0]++; } while (0)
+// per-wave timeline of ONE bond step (launch 8, step 4, group 0): slot k of half-step h of wave (cb, wv)
+#define WST(k) do { if (P.dbg && g == 0 && epoch == 8 && pp == 4 && lane == 0 && h < 8) P.dbg[((size_t)(h * 64 + cb * 4 + wv)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
+#define WST(k)
 #define CST_DECL
 #define CST(k)
 #define CST_END()
@@ -114,6 +157,8 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
     __shared__ ttx_cdfseg segc[TTX_TABSEG], segr[TTX_TABSEG];
     __shared__ double sha[8], shv[8], shm[8]; __shared__ int shi[8];
     __shared__ double pLw[64], pLk[64], pRv[64], pRk[64];   // prefix states of the two running sums per left / right row
+    // results of the rook loop, handed from wave 0 to the waves of the workgroup that own no fiber element at the current ranks
+    __shared__ struct { int ii, jj, kk, qq, hcount, rc_k, rc_q, rr_i, rr_j; double pivot, amax, bytes_half; long long neval, n_resid; } s_rook;
     const int bid = blockIdx.x;
     const int g = (bid & 7) + 8 * (bid / (8 * NB)), cb = (bid >> 3) % NB;     // cluster of group g lives on XCD g % 8
     if (g >= P.G || P.ctl[0]) return;
@@ -252,6 +297,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         // ---- lottery (:410-484): every block draws and scores all candidates (identical results, no traffic) ----
         // generator words of the two draw columns: 48271^(2*rngpos+1) and 48271^(2*(rngpos+nlot)+1), advanced from
         // step to step by the small power 48271^(2*nlot) (every thread keeps them; no shared state, no barrier)
+        if (tid == 0) s_ok = 1;                            // (read behind the rook loop; several barriers lie in between)
         const unsigned long long stepmul = ttx_minstd_pow(2ull * nlot);
         const unsigned long long sA1 = ttx_mulmod31(sA0, stepmul);
         if (zkeep) {
@@ -313,7 +359,7 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             const int i = (x - 1) % r0 + 1, j = (x - 1) / r0 + 1, k = (y - 1) % n2 + 1, q = (y - 1) / n2 + 1;
             lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
             const double *rl = XL + (size_t)(i - 1) * RS, *rq = XR + (size_t)(q - 1) * RS;
-            const double f = f_ising_c4p(m, p - 1, rl, rl + VS, par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], rq, rq + VS, pRv[q - 1], pRk[q - 1], pLw[i - 1], pLk[i - 1]);
+            const double f = F_ISING_CL(m, p - 1, rl, rl + VS, par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], rq, rq + VS, pRv[q - 1], pRk[q - 1], pLw[i - 1], pLk[i - 1]);
             ma = fmax(ma, fabs(f));
             CST(4);
             const double *c = Cp + (i - 1) + (size_t)RM * (j - 1), *w = Wq + (k - 1) + (size_t)NM * (q - 1);
@@ -342,23 +388,39 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         // ---- rook half-steps (:516-582) / piv = 0 (:492-513): own slice, then one record per block ----
         int havecol = 0, haverow = 0, crs = 0, done = 0;
         int rc_k = -1, rc_q = -1, rr_i = -1, rr_j = -1;     // pivot at which resc / resr were computed (-1: not valid)
-        int xc_k = -1, xc_q = -1, xr_i = -1, xr_j = -1;     // pivot at which xsc / xsr were loaded
         const int H = (P.piv == 0) ? 2 : 2 * P.piv;
+        const int r1u = __builtin_amdgcn_readfirstlane(r1);
+        double mxrun = 0.0;                                 // this wave's largest |value| over the half-steps of this bond step
+        // Only the waves that own fiber elements at the current ranks (and wave 0 of every workgroup) take part in the rook loop and
+        // its record exchange: at low ranks that is one wave per workgroup, and 24 idle waves polling the same four cache lines for
+        // the whole evaluation delayed the records of the working ones (2900 cycles from the last store to the end of the poll,
+        // against ~1000 in isolation: profiles/probes/probe_exchange.hip).  The others wait at the barrier behind the loop and take
+        // the results from LDS.  wact(c): participating waves of workgroup c -- the same number on every wave of the cluster.
+        auto wact = [&](int c) {
+            const int njc = (int)((long long)(c + 1) * n1 / NB) - (int)((long long)c * n1 / NB), nkc = (int)((long long)(c + 1) * n2 / NB) - (int)((long long)c * n2 / NB);
+            const int e = max(r0 * njc, nkc * r2);
+            return min(CB / 64, max(1, (e + 63) >> 6));
+        };
+        const bool rook_active = wv < wact(cb);
+        const bool slot_on = (lane < NB * (CB / 64)) && ((lane & (CB / 64 - 1)) < wact(lane / (CB / 64)));      // lane = record slot
+        if (rook_active) {
         for (int h = 0; h < H && !done; h++) {
             const bool iscol = (P.piv == 0) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);
             const int nf = iscol ? r0 * n1 : n2 * r2;
             const int nsl = iscol ? r0 * nj : nk * r2;
             double *fib = iscol ? acol : arow;
-            double *xs = iscol ? xsc : xsr;
-            if (iscol) { for (int s = tid; s < r1; s += CB) xs[s] = Wq[(kk - 1) + (size_t)NM * (qq - 1) + P.SW * s]; xc_k = kk; xc_q = qq; }
-            else       { for (int s = tid; s < r1; s += CB) xs[s] = Cp[(ii - 1) + (size_t)RM * (jj - 1) + P.SS * s]; xr_i = ii; xr_j = jj; }
+            // The r1 factor entries at the current pivot, ONE PER LANE of every wave (r1 <= 64): requested here, consumed after the
+            // evaluation (lane s of the wave supplies entry s to the ordered residual sum through v_readlane).  No LDS, no
+            // workgroup barrier: the waves of a cluster run the rook loop independently and meet only in the record exchange.
+            double xsv = 0.0;
+            if (lane < r1) xsv = iscol ? Wq[(kk - 1) + (size_t)NM * (qq - 1) + P.SW * lane] : Cp[(ii - 1) + (size_t)RM * (jj - 1) + P.SS * lane];
             crs++;
             if (iscol) havecol = 1; else haverow = 1;
             const int dn = (P.piv == 0) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));
             const bool resid = (P.piv != 0) && !dn;
             if (iscol) { rc_k = resid ? kk : -1; rc_q = qq; } else { rr_i = resid ? ii : -1; rr_j = jj; }
-            __syncthreads();
             CST(6);
+            WST(0);
             double mx = 0.0, ab = -1.0, bb = 0.0; int ix = INT_MAX;
             for (int u = tid; u < nsl; u += CB) {
                 double a;
@@ -366,12 +428,23 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     const int i = u % r0, j = jlo + u / r0, t = i + r0 * j;
                     const double *rl = XL + (size_t)i * RS, *rq = XR + (size_t)(qq - 1) * RS;
                     const double *c = Cp + i + (size_t)RM * j;
-                    a = f_ising_c4p(m, p - 1, rl, rl + VS, par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], rq, rq + VS, pRv[qq - 1], pRk[qq - 1], pLw[i], pLk[i]);
+#if TTX_CL_CF
+                    double cf[TTX_CL_CF];                // the factor entries of this element's residual, requested BEFORE the evaluation
+                    if (resid) {
+#pragma unroll
+                        for (int s = 0; s < TTX_CL_CF; s++) if (s < r1u) cf[s] = c[P.SS * s];
+                    }
+#endif
+                    a = F_ISING_CL(m, p - 1, rl, rl + VS, par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], rq, rq + VS, pRv[qq - 1], pRk[qq - 1], pLw[i], pLk[i]);
                     fib[u] = a;
                     if (resid) {
                         double b = a;
-#pragma unroll 8
-                        for (int s = 0; s < r1; s++) b = b + (-xs[s]) * c[P.SS * s];
+#if TTX_CL_CF
+#pragma unroll
+                        for (int s = 0; s < TTX_CL_CF; s++) if (s < r1u) b = b + (-mvn_lane(xsv, s)) * cf[s];
+#endif
+#pragma unroll TTX_CL_UNR
+                        for (int s = TTX_CL_CF; s < r1u; s++) b = b + (-mvn_lane(xsv, s)) * c[P.SS * s];
                         resc[u] = b;
                         const double aa = fabs(b);
                         if (aa > ab || (aa == ab && t < ix)) { ab = aa; bb = b; ix = t; }
@@ -380,12 +453,23 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                     const int k = klo + u % nk, q = u / nk, t = k + n2 * q;
                     const double *rl = XL + (size_t)(ii - 1) * RS, *rq = XR + (size_t)q * RS;
                     const double *w = Wq + k + (size_t)NM * q;
-                    a = f_ising_c4p(m, p - 1, rl, rl + VS, par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], rq, rq + VS, pRv[q], pRk[q], pLw[ii - 1], pLk[ii - 1]);
+#if TTX_CL_CF
+                    double cf[TTX_CL_CF];
+                    if (resid) {
+#pragma unroll
+                        for (int s = 0; s < TTX_CL_CF; s++) if (s < r1u) cf[s] = w[P.SW * s];
+                    }
+#endif
+                    a = F_ISING_CL(m, p - 1, rl, rl + VS, par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], rq, rq + VS, pRv[q], pRk[q], pLw[ii - 1], pLk[ii - 1]);
                     fib[u] = a;
                     if (resid) {
                         double tt = 0.0;
-#pragma unroll 8
-                        for (int s = 0; s < r1; s++) tt = tt + w[P.SW * s] * xs[s];
+#if TTX_CL_CF
+#pragma unroll
+                        for (int s = 0; s < TTX_CL_CF; s++) if (s < r1u) tt = tt + cf[s] * mvn_lane(xsv, s);
+#endif
+#pragma unroll TTX_CL_UNR
+                        for (int s = TTX_CL_CF; s < r1u; s++) tt = tt + w[P.SW * s] * mvn_lane(xsv, s);
                         const double b = a + (-1.0) * tt;
                         resr[u] = b;
                         const double aa = fabs(b);
@@ -395,61 +479,60 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 mx = fmax(mx, fabs(a));
             }
             CST(7);
+            WST(1);
             mx = wave_max(mx);
-            wave_argmax(ab, bb, ix);
-            if (lane == 0) { shm[wv] = mx; sha[wv] = ab; shv[wv] = bb; shi[wv] = ix; }
-            __syncthreads();
-            // exchange: every block publishes one tagged 32-byte record {|b|max, position, sign, tag}{fiber max, tag};
-            // wave 0 polls the NB records of this half-step (L1-bypassing 16-byte loads) and reduces them.  No fence:
-            // nothing but the records crosses blocks here (fibers stay in LDS, factors were published at the end of
-            // earlier bond steps).  Records are double-buffered by half-step parity; the tag carries the launch number.
-            ClRec *buf = (ClRec *)part + ((size_t)(hcount & 1) * P.G + g) * TTX_CLMAX;
+            wave_argmax2(ab, bb, ix);
+            WST(2);
+            // exchange: every WAVE publishes ONE tagged 16-byte record {|b|max, position, tag | sign} of its own elements and then
+            // polls the 4 NB records of this half-step itself (L1-bypassing 16-byte loads, one per lane) and reduces them -- every
+            // wave of the cluster arrives at the same result without a workgroup barrier.  A second record per exchange doubles its
+            // cost (profiles/probes/probe_exchange.hip: 1.33 us per round with two records, 0.63 us with one, 0.49 us without the
+            // sleep between polls), so the fiber maximum -- needed only by the acceptance test after the rook loop -- travels as a
+            // RUNNING maximum in a record of its own that is stored here but read once, after the loop.  No fence: nothing but the
+            // records crosses blocks here (fibers stay in LDS, factors were published at the end of earlier bond steps).  Records
+            // are double-buffered by half-step parity (a wave cannot be two exchanges ahead of another: it needs that wave's record
+            // of the exchange in between); the tag carries the launch number.
+            u4 *bufA = (u4 *)part + ((size_t)(hcount & 1) * P.G + g) * TTX_CLREC;
+            u4 *bufB = bufA + (size_t)2 * P.G * TTX_CLREC;
             const unsigned gen = ((unsigned)epoch << 20) | (unsigned)(hcount + 1);
-            if (wv == 0) {
-                if (lane == 0) {
-                    for (int x = 1; x < CB / 64; x++) {
-                        mx = fmax(mx, shm[x]);
-                        if (sha[x] > ab || (sha[x] == ab && shi[x] < ix)) { ab = sha[x]; bb = shv[x]; ix = shi[x]; }
+            mxrun = fmax(mxrun, mx);
+            if (lane == 0) {
+                const unsigned long long ua = (unsigned long long)__double_as_longlong(ab), um = (unsigned long long)__double_as_longlong(mxrun);
+                u4 ra, rb;
+                rb.x = (unsigned)um; rb.y = (unsigned)(um >> 32); rb.z = gen; rb.w = 0;
+                st16(&bufB[cb * (CB / 64) + wv], rb);
+                ra.x = (unsigned)ua; ra.y = (unsigned)(ua >> 32); ra.z = (unsigned)ix; ra.w = gen | (signbit(bb) ? 0x80000000u : 0u);
+                st16(&bufA[cb * (CB / 64) + wv], ra);
+            }
+            CST(8);
+            WST(3);
+            int ok = 1;
+            ab = -1.0; bb = 0.0; ix = INT_MAX;
+            if (slot_on) {
+                unsigned spins = 0;
+                for (;;) {
+                    const u4 ra = ld16(&bufA[lane]);
+                    if ((ra.w & 0x7fffffffu) == gen) {
+                        ab = __longlong_as_double((long long)(((unsigned long long)ra.y << 32) | ra.x));
+                        ix = (int)ra.z;
+                        bb = (ra.w & 0x80000000u) ? -ab : ab;
+                        break;
                     }
-                    const unsigned long long ua = (unsigned long long)__double_as_longlong(ab), um = (unsigned long long)__double_as_longlong(mx);
-                    u4 ra, rb;
-                    ra.x = (unsigned)ua; ra.y = (unsigned)(ua >> 32); ra.z = (unsigned)ix; ra.w = gen | (signbit(bb) ? 0x80000000u : 0u);
-                    rb.x = (unsigned)um; rb.y = (unsigned)(um >> 32); rb.z = gen; rb.w = 0;
-                    st16(&buf[cb].a, ra); st16(&buf[cb].b, rb);
-                }
-                CST(8);
-                int ok = 1;
-                mx = 0.0; ab = -1.0; bb = 0.0; ix = INT_MAX;
-                if (lane < NB) {
-                    unsigned spins = 0;
-                    for (;;) {
-                        const u4 ra = ld16(&buf[lane].a), rb = ld16(&buf[lane].b);
-                        if ((ra.w & 0x7fffffffu) == gen && rb.z == gen) {
-                            ab = __longlong_as_double((long long)(((unsigned long long)ra.y << 32) | ra.x));
-                            mx = __longlong_as_double((long long)(((unsigned long long)rb.y << 32) | rb.x));
-                            ix = (int)ra.z;
-                            bb = (ra.w & 0x80000000u) ? -ab : ab;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 22)) { ok = 0; break; }
-                        if ((spins & 1023u) == 0 && __hip_atomic_load(P.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { ok = 0; break; }
-                    }
-                }
-                ok = __all(ok);
-                mx = wave_max(mx);
-                wave_argmax(ab, bb, ix);
-                if (lane == 0) {
-                    if (!ok) __hip_atomic_store(P.cl_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    s_ok = ok; shm[0] = mx; sha[0] = ab; shv[0] = bb; shi[0] = ix;
+                    if (++spins > 64u) __builtin_amdgcn_s_sleep(1);
+                    if (spins > (1u << 22)) { ok = 0; break; }
+                    if ((spins & 1023u) == 0 && __hip_atomic_load(P.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { ok = 0; break; }
                 }
             }
-            __syncthreads();
-            if (!s_ok) { if (tid == 0) P.ctl[0] = 1; return; }      // aborted: the tail kernels of this sweep do nothing
+            WST(4);
+            ok = __all(ok);
+            wave_argmax2(ab, bb, ix);
+            WST(5);
+            if (!ok) {                                   // aborted: the tail kernels of this sweep do nothing
+                if (lane == 0) { __hip_atomic_store(P.cl_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); P.ctl[0] = 1; *(volatile int *)&s_ok = 0; }
+                return;
+            }
             CST(9);
-            mx = shm[0]; ab = sha[0]; bb = shv[0]; ix = shi[0];
             hcount++;
-            if (P.piv != 0) amax = fmax(amax, mx);           // the piv = 0 branch (:492-513) does not touch amax
             neval += nf;
             bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
             n_resid += resid ? 1 : 0;
@@ -461,7 +544,39 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                 pivot = bb;
             }
         }
+        if (P.piv != 0) {            // the fiber maxima of the bond step (:531 / :564; the piv = 0 branch :492-513 does not touch amax):
+            // the running maxima that every wave stored next to its record of the LAST exchange
+            u4 *bufB = (u4 *)part + ((size_t)((hcount - 1) & 1) * P.G + g) * TTX_CLREC + (size_t)2 * P.G * TTX_CLREC;
+            const unsigned gen = ((unsigned)epoch << 20) | (unsigned)hcount;
+            double mx = 0.0; int ok = 1;
+            if (slot_on) {
+                unsigned spins = 0;
+                for (;;) {
+                    const u4 rb = ld16(&bufB[lane]);
+                    if (rb.z == gen) { mx = __longlong_as_double((long long)(((unsigned long long)rb.y << 32) | rb.x)); break; }
+                    if (++spins > 64u) __builtin_amdgcn_s_sleep(1);
+                    if (spins > (1u << 22)) { ok = 0; break; }
+                    if ((spins & 1023u) == 0 && __hip_atomic_load(P.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { ok = 0; break; }
+                }
+            }
+            ok = __all(ok);
+            if (!ok) {
+                if (lane == 0) { __hip_atomic_store(P.cl_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); P.ctl[0] = 1; *(volatile int *)&s_ok = 0; }
+                return;
+            }
+            amax = fmax(amax, wave_max(mx));
+        }
+        if (tid == 0) {
+            s_rook.ii = ii; s_rook.jj = jj; s_rook.kk = kk; s_rook.qq = qq; s_rook.hcount = hcount; s_rook.rc_k = rc_k; s_rook.rc_q = rc_q;
+            s_rook.rr_i = rr_i; s_rook.rr_j = rr_j; s_rook.pivot = pivot; s_rook.amax = amax; s_rook.bytes_half = bytes_half; s_rook.neval = neval; s_rook.n_resid = n_resid;
+        }
+        }   // rook_active
         __syncthreads();
+        if (!*(volatile int *)&s_ok) return;                // the working waves gave up (bounded wait expired) and have left
+        if (!rook_active) {
+            ii = s_rook.ii; jj = s_rook.jj; kk = s_rook.kk; qq = s_rook.qq; hcount = s_rook.hcount; rc_k = s_rook.rc_k; rc_q = s_rook.rc_q;
+            rr_i = s_rook.rr_i; rr_j = s_rook.rr_j; pivot = s_rook.pivot; amax = s_rook.amax; bytes_half = s_rook.bytes_half; neval = s_rook.neval; n_resid = s_rook.n_resid;
+        }
         CST(10);
         // ---- acceptance and in-place append (:598-758): every block appends its own slice ----
         int *tape = P.tape + ((size_t)g * (m + 2) + p) * 4;
@@ -471,11 +586,9 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
         } else {
             const int i0 = ii - 1, j0 = jj - 1, k0 = kk - 1, q0 = qq - 1;
             double *gI = inv_ptr(P, g, p, first);
-            // the factor entries at the final pivot were loaded by the last column / row half-step; reload only if not
-            const bool haveC = (xc_k == kk && xc_q == qq), haveR = (xr_i == ii && xr_j == jj);
-            if (!haveC) for (int s = tid; s < r1; s += CB) xsc[s] = Wq[k0 + (size_t)NM * q0 + P.SW * s];
-            if (!haveR) for (int s = tid; s < r1; s += CB) xsr[s] = Cp[i0 + (size_t)RM * j0 + P.SS * s];
-            if (!haveC || !haveR) __syncthreads();
+            // the factor entries at the final pivot (the half-steps keep theirs in registers)
+            for (int s = tid; s < r1; s += CB) { xsc[s] = Wq[k0 + (size_t)NM * q0 + P.SW * s]; xsr[s] = Cp[i0 + (size_t)RM * j0 + P.SS * s]; }
+            __syncthreads();
             // role E first part: packed LU from the OLD factors (:649-660)
             if (cb == 0)
                 for (int s = tid; s < r1; s += CB) { gI[r1 * r1 + s] = xsr[s]; gI[r1 * r1 + r1 + s] = xsc[s]; }

@@ -75,6 +75,7 @@ struct GroupState {
 struct LotPart { double ab, bv, ma; int il, i, j, k, q, pad; };
 
 #define TTX_CLMAX 16            // most workgroups one bond group's cluster may have
+#define TTX_CLREC (4 * TTX_CLMAX) // arg-max records per group and half-step parity: one per WAVE of the cluster (4 waves per workgroup)
 struct ClPart { double ab, bb, mx; int ix, pad; };
 
 struct DevProb {
@@ -161,5 +162,6 @@ struct DevProb {
     unsigned *cl_ctr;              // [G]
     int *cl_abort;                 // [1]
     int cl_test_abort;             // test hook: block (group 0, block 0) raises the abort flag in launch number cl_test_abort (0: never)
-    struct ClPart *cl_part;        // [2][G][TTX_CLMAX]
+    struct ClPart *cl_part;        // [2][G][TTX_CLREC]
+    long long *dbg;                // -DTTX_STAMPS builds: per-wave cycle stamps of one bond step of the cluster kernel (group 0)
 };

@@ -612,8 +612,11 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         if (h->cluster) {
             unsigned *ctr; ClPart *cp;
             rc = dev_alloc(h, &ctr, (size_t)h->G); if (rc) { ttx_destroy(h); return rc; }
-            rc = dev_alloc(h, &cp, (size_t)2 * h->G * TTX_CLMAX); if (rc) { ttx_destroy(h); return rc; }
+            rc = dev_alloc(h, &cp, (size_t)2 * h->G * TTX_CLREC); if (rc) { ttx_destroy(h); return rc; }
             P.cl_ctr = ctr; P.cl_part = cp;
+#ifdef TTX_STAMPS
+            if (getenv("TTX_DBG_WAVES")) { long long *dbg; rc = dev_alloc(h, &dbg, (size_t)8 * 64 * 8); if (rc) { ttx_destroy(h); return rc; } P.dbg = dbg; }
+#endif
             HIPCHECK(hipHostMalloc((void **)&h->h_abort, sizeof(int)));
             *h->h_abort = 0;
             P.cl_abort = h->h_abort;
@@ -1518,6 +1521,23 @@ static int run_impl(ttx_engine *h)
     if ((rc = readback(h))) return rc;
     HIPCHECK(hipGetLastError());
 #ifdef TTX_STAMPS
+    if (P.dbg) {   // per-wave cycle stamps of one bond step of the cluster kernel (WST in ttx_cluster.h), relative to the earliest one
+        std::vector<long long> hb(8 * 64 * 8);
+        HIPCHECK(hipMemcpy(hb.data(), P.dbg, sizeof(long long) * hb.size(), hipMemcpyDeviceToHost));
+        long long t0 = 0;
+        for (long long v : hb) if (v && (!t0 || v < t0)) t0 = v;
+        for (int hh = 0; hh < 8; hh++) {
+            bool any = false;
+            for (int w = 0; w < 64; w++) if (hb[((size_t)hh * 64 + w) * 8]) any = true;
+            if (!any) continue;
+            fprintf(stderr, "half-step %d (cycles since the first stamp; per wave: start eval-done reduced published polled reduced2)\n", hh);
+            for (int w = 0; w < 64; w++) {
+                const long long *e = &hb[((size_t)hh * 64 + w) * 8];
+                if (!e[0]) continue;
+                fprintf(stderr, "  blk %d wave %d: %7lld %7lld %7lld %7lld %7lld %7lld\n", w / 4, w % 4, e[0] - t0, e[1] - t0, e[2] - t0, e[3] - t0, e[4] - t0, e[5] - t0);
+            }
+        }
+    }
     {   // debug build: average wall_clock64 ticks (10 ns) per phase of the lottery (0) and half-step (1) kernels
         GroupState g0s;
         HIPCHECK(hipMemcpy(&g0s, P.gs, sizeof(GroupState), hipMemcpyDeviceToHost));

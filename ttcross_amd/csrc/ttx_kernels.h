@@ -502,6 +502,49 @@ __device__ __forceinline__ void chain8v(const double *p, int n, STEP step)
         for (int k = 0; k < 8; k++) if (k < rem) step(x[k]);
     }
 }
+// chain8v with the LDS reads of the NEXT chunk issued before the dependent steps of the current one (two register sets, the
+// loop unrolled by two so that they swap roles without copies).  Same values in the same order.
+__device__ __forceinline__ void ld8d(const double *p, double (&x)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const Double2 t = *reinterpret_cast<const Double2 *>(p + 2 * k); x[2 * k] = t.a; x[2 * k + 1] = t.b; }
+}
+template <bool DESC, class STEP>
+__device__ __forceinline__ void chain8p(const double *p, int n, STEP step)
+{
+    if (n <= 0) return;
+    const int nfull = n >> 3, rem = n & 7;
+    double x[8], y[8];
+    auto base = [&](int ch) { return 8 * (DESC ? nfull - 1 - ch : ch); };
+    if (DESC && rem) {
+        ld8d(p + 8 * nfull, x);
+        if (nfull) ld8d(p + base(0), y);
+#pragma unroll
+        for (int k = 7; k >= 0; k--) if (k < rem) step(x[k]);
+    } else if (nfull) ld8d(p + base(0), y);
+    int ch = 0;
+    for (; ch + 1 < nfull; ch += 2) {
+        ld8d(p + base(ch + 1), x);
+#pragma unroll
+        for (int k = 0; k < 8; k++) step(y[DESC ? 7 - k : k]);
+        if (ch + 2 < nfull) ld8d(p + base(ch + 2), y); else if (!DESC && rem) ld8d(p + 8 * nfull, y);
+#pragma unroll
+        for (int k = 0; k < 8; k++) step(x[DESC ? 7 - k : k]);
+    }
+    if (ch < nfull) {                      // one full chunk left (in y); the ascending remainder is requested under it
+        if (!DESC && rem) ld8d(p + 8 * nfull, x);
+#pragma unroll
+        for (int k = 0; k < 8; k++) step(y[DESC ? 7 - k : k]);
+        if (!DESC && rem) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (k < rem) step(x[k]);
+        }
+    } else if (!DESC && rem) {             // the remainder sits in y (requested above) -- or nothing was requested yet (nfull == 0)
+        if (nfull == 0) ld8d(p, y);
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < rem) step(y[k]);
+    }
+}
 // dims 1..A: (an, aw); dim A+1: (sn, sw); dims A+2..m: (bn, bw)   [n = node values, w = weight values]
 __device__ __forceinline__ double f_ising_c3v(int m, int A, const double *an, const double *aw, double sn, double sw,
                                               const double *bn, const double *bw)
@@ -811,7 +854,7 @@ __global__ __launch_bounds__(256) void k_reset(DevProb P, size_t SB, size_t QB)
     if (P.cl_ctr) {
         for (size_t x = t0; x < (size_t)P.G; x += nt) P.cl_ctr[x] = 0u;
         ClPart z; z.ab = 0.0; z.bb = 0.0; z.mx = 0.0; z.ix = 0; z.pad = 0;
-        for (size_t x = t0; x < (size_t)2 * P.G * TTX_CLMAX; x += nt) P.cl_part[x] = z;
+        for (size_t x = t0; x < (size_t)2 * P.G * TTX_CLREC; x += nt) P.cl_part[x] = z;
     }
     for (size_t g = t0; g < (size_t)P.G; g += nt) {
         GroupState &gs = P.gs[g];
