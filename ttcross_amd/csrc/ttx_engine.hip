@@ -2016,6 +2016,15 @@ static void push_ranks(ttx_engine *h)
     (void)hipStreamSynchronize(h->stream);
 }
 static inline dim3 g1(size_t n) { return dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)); }
+// threads of the one-workgroup factorisation kernels (a multiple of 64, at most 1024): the kernels are chains of short phases
+// separated by workgroup barriers, whose cost grows with the number of waves -- TTX_QR_THREADS / TTX_JAC_THREADS override
+static int tt_threads(const char *env, int dflt)
+{
+    int v = dflt;
+    if (const char *e = getenv(env)) v = atoi(e);
+    v = std::max(64, std::min(1024, v)) & ~63;
+    return v;
+}
 static int gemm(ttx_engine *h, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc)
 {
     hipLaunchKernelGGL(k_gemm_mfma, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, h->stream, M, N, K, A, lda, B, ldb, C, ldc);
@@ -2050,12 +2059,12 @@ static bool qr_tsqr(ttx_engine *h, int m, int n, double *A, double *R, double *t
         double *Rst = (l + 1 < lv.size()) ? lv[l + 1].M : M;                    // the next level's matrix (P n x n)
         const size_t lds = sizeof(double) * qr_panel_lds_doubles(L.rbs, n);
         if ((*rc_out = ensure_lds(reinterpret_cast<const void *>(k_qr_panel), lds, a_qp))) return true;
-        hipLaunchKernelGGL(k_qr_panel, dim3(L.P), dim3(1024), lds, h->stream, L.rows, n, L.rbs, L.M, L.Q, Rst, L.P * n);
+        hipLaunchKernelGGL(k_qr_panel, dim3(L.P), dim3(tt_threads("TTX_QR_THREADS", 1024)), lds, h->stream, L.rows, n, L.rbs, L.M, L.Q, Rst, L.P * n);
     }
     {   // top: one workgroup, in place: M -> Q_top (rows x n), R (n x n)
         const size_t lds_all = sizeof(double) * ((size_t)rows + n + 4 + (size_t)rows * n);
         if ((*rc_out = ensure_lds(reinterpret_cast<const void *>(k_qr<true>), lds_all, a_q1))) return true;
-        hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(1024), lds_all, h->stream, rows, n, M, R, tau);
+        hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(tt_threads("TTX_QR_THREADS", 1024)), lds_all, h->stream, rows, n, M, R, tau);
     }
     // explicit Q, top down: Qacc(level l) = blockdiag(Q_p) * Qacc(level l+1); level l's own matrix buffer takes the result
     const double *Qup = M; int ldup = rows;
@@ -2078,7 +2087,7 @@ static int qr(ttx_engine *h, int m, int n, double *A, double *R, double *tau)
     static size_t a_q0 = 0, a_q1 = 0;
     if (lds_all <= 150 * 1024) {
         if (int rc = ensure_lds(reinterpret_cast<const void *>(k_qr<true>), lds_all, a_q1)) return rc;
-        hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(1024), lds_all, h->stream, m, n, A, R, tau);
+        hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(tt_threads("TTX_QR_THREADS", 1024)), lds_all, h->stream, m, n, A, R, tau);
     } else {
         if (int rc = ensure_lds(reinterpret_cast<const void *>(k_qr<false>), lds, a_q0)) return rc;
         hipLaunchKernelGGL(k_qr<false>, dim3(1), dim3(1024), lds, h->stream, m, n, A, R, tau);
@@ -2091,7 +2100,7 @@ static int jacobi(ttx_engine *h, int p, int q, double *X, double *V, double *sv,
     const int in_lds = lds <= 140 * 1024;
     static size_t a_j = 0;
     if (in_lds) { if (int rc = ensure_lds(reinterpret_cast<const void *>(k_jacobi_svd), lds, a_j)) return rc; }
-    hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(1024), in_lds ? lds : 0, h->stream, p, q, X, V, sv, perm, info, 1, tol, rmax, in_lds);
+    hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(tt_threads("TTX_JAC_THREADS", 1024)), in_lds ? lds : 0, h->stream, p, q, X, V, sv, perm, info, 1, tol, rmax, in_lds);
     return TTX_OK;
 }
 static int sumsq(ttx_engine *h, size_t n, const double *x, double *out_host)
