@@ -136,11 +136,14 @@ int ttx_quad(ttx_engine *h, const double *w, double *val);
 
 /* dtt_accchk(nlot, arg, einf, efro, ainf, afro, fun, par, pivot), lib/dmrgg.f90:1081-1166: nlot random samples of
  * |fun - TT| drawn from the run-time RNG stream where dtt_dmrgg left it (irnd, lib/rnd.f90:83-88); element
- * evaluation as dtt_ijk (lib/tt.f90:630-652).  Single-process engines only (as in the reference, every rank
- * would need all cores).  pivot: d ints (worst sample) or NULL. */
+ * evaluation as dtt_ijk (lib/tt.f90:630-652).  As in the reference every rank needs all cores: on a multi-process engine the
+ * call is COLLECTIVE and works on a replica of the job's train (ttx_replicate); every process gets the same numbers.
+ * pivot: d ints (worst sample) or NULL. */
 int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efro, double *ainf, double *afro, int32_t *pivot);
 
-/* tt_lib utilities on the tensor train resident on the device; single-process engines only.
+/* tt_lib utilities on the tensor train resident on the device.  ttx_norm / ttx_dot / ttx_zquad / ttx_write on a
+ * multi-process engine are COLLECTIVE (ztt_quad folds per-process partial products, lib/dmrgg.f90:1418-1523; the others work on a
+ * replica, ttx_replicate); ttx_ort / ttx_svd / ttx_ijk change or address single cores and take single-process engines (or a replica).
  * ttx_ort  : dtt_ort  (lib/tt.f90:130-198)  left-to-right Householder QR, in place
  * ttx_svd  : dtt_svd  (lib/tt.f90:307-368)  rounding: ort, then truncated SVD right-to-left; tol relative
  *            (lib/mat.f90:433-458 chop), rmax <= 0: absent
@@ -154,8 +157,14 @@ int ttx_dot(ttx_engine *hx, ttx_engine *hy, double *val);
 int ttx_ijk(ttx_engine *h, const int32_t *ind, double *val);
 /* ztt_quad (lib/dmrgg.f90:1418-1523) of the (real) resident TT with COMPLEX rank-1 weights, batched over nf weight
  * sets (the 32 frequencies of test_crs_chf.f90:153-168 in one call): w = nf blocks of sum(n) interleaved (re, im)
- * doubles, out = nf (re, im) pairs.  Single-process engines only. */
+ * doubles, out = nf (re, im) pairs.  Multi-process engines: collective, the value on every process. */
 int ttx_zquad(ttx_engine *h, int32_t nf, const double *w, double *out);
+
+/* The finalised train of a MULTI-PROCESS job gathered onto EVERY process as a new single-process engine (same integrand, ranks,
+ * RNG position; *out is owned by the caller: ttx_destroy).  Collective over the job's transport (each process contributes the
+ * cores it holds; the others arrive by a SUM all-reduce into zero-filled slots, which is exact).  The reference's dtt_accchk,
+ * norm, dot_product, ort, svd and dtt_write expect a type(dtt) with all cores (lib/tt.f90; lib/dmrgg.f90:1081-1166). */
+int ttx_replicate(ttx_engine *h, ttx_engine **out);
 
 /* Tensor trains that do not come from a sweep.
  * ttx_from_tt : upload a train given as compact column-major cores (d blocks r(k-1)*n(k)*r(k), concatenated) and make

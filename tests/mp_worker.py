@@ -76,6 +76,39 @@ def one_job():
             ncores += 1
             if not np.array_equal(tt.core(k), oo["cores"][k - 1]):
                 bad.append(f"core{k}")
+    if os.environ.get("TTX_MP_UTILS") == "1":
+        # collective post-processing on the multi-process engine against the SAME job as one process (validated against the oracle by
+        # the single-process tests): dtt_accchk exact, norm / dot_product 1e-12, ztt_quad 1e-13, dtt_write byte-identical
+        import tempfile
+        one = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng, device=dev).run()
+        rng = np.random.default_rng(5)
+        wz = rng.standard_normal((3, int(np.sum(s["n"])))) + 1j * rng.standard_normal((3, int(np.sum(s["n"]))))
+        a1, a2 = tt.accchk(700), one.accchk(700)
+        if any(a1[k] != a2[k] for k in ("einf", "efro", "ainf", "afro")) or not np.array_equal(a1["pivot"], a2["pivot"]):
+            bad.append(f"accchk {a1} vs {a2}")
+        n1, n2 = tt.norm(), one.norm()
+        if abs(n1 - n2) > 1e-12 * abs(n2):
+            bad.append(f"norm {n1!r} vs {n2!r}")
+        d1, d2 = tt.dot(one), one.dot(one)
+        if abs(d1 - d2) > 1e-12 * abs(d2):
+            bad.append(f"dot {d1!r} vs {d2!r}")
+        z1, z2 = tt.zquad(wz), one.zquad(wz)
+        if np.max(np.abs(z1 - z2)) > 1e-13 * np.max(np.abs(z2)):
+            bad.append(f"zquad {z1} vs {z2}")
+        rep = tt.replicate()
+        if not all(np.array_equal(rep.core(k), one.core(k)) for k in range(1, tt.d + 1)):
+            bad.append("replica cores")
+        rep.close()
+        with tempfile.TemporaryDirectory() as td:
+            f1, f2 = os.path.join(td, f"a{rank}.tt"), os.path.join(td, f"b{rank}.tt")
+            tt.write(f1)
+            if rank == 0:
+                one.write(f2)
+                b1, b2 = open(f1, "rb").read(), open(f2, "rb").read()
+                if b1 != b2:
+                    k = next((i for i in range(min(len(b1), len(b2))) if b1[i] != b2[i]), -1)
+                    bad.append(f"dtt_write file: sizes {len(b1)} / {len(b2)}, first difference at byte {k}")
+        one.close()
     print(f"[rank {rank}/{world}] groups={ng} transport={transport} value={val:.16e} neval={tt.neval} cores_held={ncores} "
           f"path={tt.sweep_path()} time={tt.seconds*1e3:.2f}ms {'OK' if not bad else 'MISMATCH ' + '; '.join(bad[:6])}", flush=True)
     if dist is not None:

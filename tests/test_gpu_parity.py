@@ -366,6 +366,19 @@ def test_multi_process_shm_transport(world, args, pipeline):
         assert rc == 0 and " OK" in o, o[-2000:] + e[-2000:]
 
 
+@pytest.mark.parametrize("world,args", [(2, "c 6 33 20 2 4"), (3, "d 8 33 10 2 3"), (4, "c 16 51 32 2 8")], ids=["w2_c6_g4", "w3_d8_g3", "w4_c16_g8"])
+def test_multi_process_post_processing(world, args):
+    """dtt_accchk, norm, dot_product, ztt_quad, dtt_write and ttx_replicate on the engines of a MULTI-PROCESS job (they used to be
+    refused there): collective calls over the job's transport, compared inside every worker with the same job run as one process --
+    accchk identical, norm / dot 1e-12, ztt_quad 1e-13, the replica's cores and the written file identical."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = _spawn_ranks(world, [sys.executable, os.path.join(root, "tests", "mp_worker.py")] + args.split() + ["shm"], {"TTX_MP_UTILS": "1"})
+    for rc, o, e in outs:
+        assert rc == 0 and " OK" in o, o[-3000:] + e[-3000:]
+
+
 def test_shm_transport_survives_stale_and_reused_segment_names():
     """The attach handshake of ttx_comm_init_shm (a nonce per initialisation): (1) a job whose processes die without closing
     leaves its segment behind under the name -- ready = 1, handshake over --; the next job under the SAME name must not join

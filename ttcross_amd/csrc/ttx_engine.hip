@@ -1651,6 +1651,99 @@ static int owner_of_core(const ttx_engine *h, int k)
     }
     return -1;
 }
+static double *core_dev(const ttx_engine *h, int k)
+{
+    const int g = owner_of_core(h, k), first = h->own[h->g0 + g];
+    return h->P.arg + ((size_t)g * h->NC + (k - first)) * h->P.CS;
+}
+static void push_ranks(ttx_engine *h)
+{
+    std::vector<int32_t> rr((size_t)h->G * (h->d + 2), 1);
+    for (int g = 0; g < h->G; g++) for (int p = 0; p <= h->d; p++) rr[(size_t)g * (h->d + 2) + p] = h->rfinal[p];
+    (void)hipMemcpyAsync(h->P.r, rr.data(), sizeof(int32_t) * rr.size(), hipMemcpyHostToDevice, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+}
+// all-reduce (sum) of a device buffer of any length over the processes of the job, in place: the host transports stage through a
+// pinned slot of red_cap doubles, so the buffer goes in pieces
+static int allreduce_big(ttx_engine *h, double *buf, size_t count)
+{
+    if (h->W == 1) return TTX_OK;
+    const size_t piece = h->comm ? count : std::max<size_t>(1, h->red_cap);
+    int inflight = 0;
+    for (size_t o = 0; o < count; o += piece) {
+        if (int rc = allreduce_dev(h, buf + o, buf + o, std::min(piece, count - o), 0)) return rc;
+        // host transports: a reduction's descriptor and pinned slot are recycled after NRED enqueues -- drain before that
+        if (!h->comm && ++inflight >= ttx_engine::NRED - 2) { HIPCHECK(hipStreamSynchronize(h->stream)); inflight = 0; }
+    }
+    return TTX_OK;
+}
+// The finalised train of a MULTI-PROCESS job on every process, as a new single-process engine with the same integrand (`out`):
+// each process copies the cores it holds into its slots of the new engine's core array and a SUM all-reduce over the job's transport
+// fills in the others (their slots hold -0.0 here, the neutral element of fp addition for every value).  dtt_accchk, norm, dot_product, ort, svd and dtt_write of the
+// reference work on a `type(dtt)` that holds ALL cores (lib/tt.f90, lib/dmrgg.f90:1081-1166): on a multi-process engine they go
+// through this copy.  Collective: every process of the job must call it.
+extern "C" int ttx_replicate(ttx_engine *h, ttx_engine **out)
+{
+    if (!h || !out) return fail(TTX_EINVAL, "ttx_replicate: null argument");
+    *out = nullptr;
+    if (!h->ran) return fail(TTX_ESTATE, "ttx_replicate: run dtt_dmrgg first");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    const int d = h->d;
+    ttx_config c = h->cfg;
+    std::vector<int32_t> nn(h->n1.begin() + 1, h->n1.begin() + 1 + d);
+    std::vector<double> qw;
+    c.n = nn.data(); c.par = h->par.empty() ? nullptr : h->par.data(); c.aux = h->aux.empty() ? nullptr : h->aux.data(); c.naux = (int32_t)h->aux.size();
+    c.quadw = nullptr;
+    if (!h->quadw.empty()) { for (int k = 1; k <= d; k++) for (int j = 0; j < h->n1[k]; j++) qw.push_back(h->quadw[(size_t)k * h->NM + j]); c.quadw = qw.data(); }
+    c.nproc = 1; c.mybonds = nullptr; c.world_rank = 0; c.world_size = 1; c.verbose = 0; c.arith = h->P.arith;
+    ttx_engine *e = nullptr;
+    int rc = create_impl(&e, &c, h->cfg.fun_id == 0);
+    if (rc) return rc;
+    e->hfun = h->hfun; e->hfun_par = h->hfun_par;
+    if (e->RM != h->RM || e->NM != h->NM) { ttx_destroy(e); return fail(TTX_EHIP, "ttx_replicate: layout mismatch"); }
+    const size_t CS = h->P.CS;
+    // slots of the other processes' cores hold -0.0: x + (-0.0) = x for EVERY x, also for x = -0.0 (x + (+0.0) would turn it into +0.0)
+    hipLaunchKernelGGL(k_fill_const, dim3(1024), dim3(256), 0, h->stream, (size_t)d * CS, e->P.arg, -0.0);
+    for (int k = 1; k <= d; k++) {
+        if (owner_of_core(h, k) < 0) continue;
+        HIPCHECK(hipMemcpyAsync(e->P.arg + (size_t)(k - 1) * CS, core_dev(h, k), sizeof(double) * CS, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if ((rc = allreduce_big(h, e->P.arg, (size_t)d * CS))) { ttx_destroy(e); return rc; }
+    // the run-time RNG stream continues where rank 0 of the reference left it (dtt_accchk draws from it): the position of the job's
+    // FIRST bond group, handed to every process through the same kind of all-reduce (an integer below 2^53 is exact in a double)
+    unsigned long long rp = 0;
+    HIPCHECK(hipMemcpyAsync(&rp, &h->P.gs[0].rngpos, sizeof(rp), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->W > 1) {
+        double v = (h->g0 == 0) ? (double)rp : -0.0;
+        double *dv = e->P.redsend;                      // a few doubles of the replica, not in use yet
+        HIPCHECK(hipMemcpyAsync(dv, &v, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if ((rc = allreduce_dev(h, dv, dv, 1, 0))) { ttx_destroy(e); return rc; }
+        HIPCHECK(hipMemcpyAsync(&v, dv, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        rp = (unsigned long long)v;
+    }
+    if (h->cb_error) { ttx_destroy(e); return fail(TTX_EHIP, "host transport: a sendrecv / allreduce callback failed"); }
+    HIPCHECK(hipMemcpy(&e->P.gs[0].rngpos, &rp, sizeof(rp), hipMemcpyHostToDevice));
+    e->rfinal = h->rfinal; e->neval = h->neval; e->ran = true;
+    push_ranks(e);
+    *out = e;
+    return TTX_OK;
+}
+// run `fn` on a replica of a multi-process engine's train
+template <class FN>
+static int with_replica(ttx_engine *h, FN fn)
+{
+    ttx_engine *e = nullptr;
+    int rc = ttx_replicate(h, &e);
+    if (rc) return rc;
+    rc = fn(e);
+    const std::string msg = g_err;
+    ttx_destroy(e);
+    if (rc) g_err = msg;
+    return rc;
+}
+
 extern "C" int64_t ttx_core_size(const ttx_engine *h, int k)
 {
     if (!h || !h->ran || k < 1 || k > h->d || owner_of_core(h, k) < 0) return 0;
@@ -1725,7 +1818,10 @@ static_assert(sizeof(TTFileHead) == 128, "stream header is 128 bytes");
 extern "C" int ttx_write(const ttx_engine *h, const char *path)
 {
     if (!h || !path || !h->ran) return fail(TTX_ESTATE, "dtt_write: no tensor train to write");
-    if (h->W > 1) return fail(TTX_EINVAL, "dtt_write: single-process engines only");
+    if (h->W > 1) {     // collective: every process takes part in the replica, rank 0 writes the file
+        ttx_engine *hh = const_cast<ttx_engine *>(h);
+        return with_replica(hh, [&](ttx_engine *e) { return hh->wrank == 0 ? ttx_write(e, path) : TTX_OK; });
+    }
     const int d = h->d;
     size_t sz = 0;
     for (int k = 1; k <= d; k++) sz += (size_t)h->rfinal[k - 1] * h->n1[k] * h->rfinal[k];
@@ -1975,7 +2071,8 @@ static int accchk_impl(ttx_engine *h, int nlot, double *einf, double *efro, doub
 extern "C" int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efro, double *ainf, double *afro, int32_t *pivot)
 {
     if (!h || !einf || !efro || !ainf || !afro || !h->ran) return fail(TTX_ESTATE, "ttx_accchk: run first");
-    if (h->W > 1) return fail(TTX_EINVAL, "dtt_accchk: every rank needs all cores; single-process engines only");
+    if (h->W > 1)       // every rank needs all cores: the check runs on a replica of the job's train (identical result on every process)
+        return with_replica(h, [&](ttx_engine *e) { return ttx_accchk(e, nlot, einf, efro, ainf, afro, pivot); });
     if (nlot < 1) return fail(TTX_EINVAL, "dtt_accchk: nlot must be positive");
     if (h->cfg.fun_id == 0) return fail(TTX_ESTATE, "dtt_accchk: this engine holds a loaded tensor train and has no integrand");
     HIPCHECK(hipSetDevice(h->cfg.device));
@@ -1990,11 +2087,6 @@ extern "C" int ttx_accchk(ttx_engine *h, int32_t nlot, double *einf, double *efr
 }
 
 // ---- tt_lib utilities (ort / svd / norm / dot) -------------------------------------------------------------
-static double *core_dev(const ttx_engine *h, int k)
-{
-    const int g = owner_of_core(h, k), first = h->own[h->g0 + g];
-    return h->P.arg + ((size_t)g * h->NC + (k - first)) * h->P.CS;
-}
 static int tt_prepare(ttx_engine *h, const char *who)
 {
     if (!h || !h->ran) return fail(TTX_ESTATE, "%s: run dtt_dmrgg first", who);
@@ -2007,13 +2099,6 @@ static int tt_prepare(ttx_engine *h, const char *who)
         if ((rc = dev_alloc(h, &h->Sm, 8 * RM * RM + 4 * RM + 16)) || (rc = dev_alloc(h, &h->Si, 2 * RM + 16))) return rc;
     }
     return TTX_OK;
-}
-static void push_ranks(ttx_engine *h)
-{
-    std::vector<int32_t> rr((size_t)h->G * (h->d + 2), 1);
-    for (int g = 0; g < h->G; g++) for (int p = 0; p <= h->d; p++) rr[(size_t)g * (h->d + 2) + p] = h->rfinal[p];
-    (void)hipMemcpyAsync(h->P.r, rr.data(), sizeof(int32_t) * rr.size(), hipMemcpyHostToDevice, h->stream);
-    (void)hipStreamSynchronize(h->stream);
 }
 static inline dim3 g1(size_t n) { return dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)); }
 // threads of the one-workgroup factorisation kernels (a multiple of 64, at most 1024): the kernels are chains of short phases
@@ -2044,7 +2129,7 @@ static bool qr_tsqr(ttx_engine *h, int m, int n, double *A, double *R, double *t
     std::vector<Lvl> lv;
     double *Sbuf = h->Wc, *Tbuf = h->Wd;
     int rows = m; double *M = A;
-    while ((size_t)rows * n + rows + n + 4 > budget) {                          // until one workgroup's LDS takes the rest
+    while ((size_t)rows * n + rows + 2 * n + 4 > budget) {                      // until one workgroup's LDS takes the rest
         const int P = (rows + RB - 1) / RB, rbs = (rows + P - 1) / P;
         if (rows - (P - 1) * rbs < n) return false;                             // a last panel shorter than n: keep the one-workgroup path
         Lvl L{rows, P, rbs, M, lv.empty() ? h->Wb : Tbuf};
@@ -2062,9 +2147,9 @@ static bool qr_tsqr(ttx_engine *h, int m, int n, double *A, double *R, double *t
         hipLaunchKernelGGL(k_qr_panel, dim3(L.P), dim3(tt_threads("TTX_QR_THREADS", 1024)), lds, h->stream, L.rows, n, L.rbs, L.M, L.Q, Rst, L.P * n);
     }
     {   // top: one workgroup, in place: M -> Q_top (rows x n), R (n x n)
-        const size_t lds_all = sizeof(double) * ((size_t)rows + n + 4 + (size_t)rows * n);
+        const size_t lds_all = sizeof(double) * ((size_t)rows + 2 * n + 4 + (size_t)rows * n);
         if ((*rc_out = ensure_lds(reinterpret_cast<const void *>(k_qr<true>), lds_all, a_q1))) return true;
-        hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(tt_threads("TTX_QR_THREADS", 1024)), lds_all, h->stream, rows, n, M, R, tau);
+        hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(tt_threads("TTX_QRTOP_THREADS", 1024)), lds_all, h->stream, rows, n, M, R, tau);
     }
     // explicit Q, top down: Qacc(level l) = blockdiag(Q_p) * Qacc(level l+1); level l's own matrix buffer takes the result
     const double *Qup = M; int ldup = rows;
@@ -2083,7 +2168,7 @@ static int qr(ttx_engine *h, int m, int n, double *A, double *R, double *tau)
     const size_t lds = sizeof(double) * ((size_t)m + n + 4);
     if (lds > 150 * 1024) return fail(TTX_EINVAL, "dtt_ort: unfolding with %d rows does not fit the LDS-staged reflector", m);
     // small unfoldings are factored entirely inside LDS; larger ones stream the panel from L2 with threads mapped to rows
-    const size_t lds_all = lds + sizeof(double) * (size_t)m * n;
+    const size_t lds_all = lds + sizeof(double) * ((size_t)m * n + n);
     static size_t a_q0 = 0, a_q1 = 0;
     if (lds_all <= 150 * 1024) {
         if (int rc = ensure_lds(reinterpret_cast<const void *>(k_qr<true>), lds_all, a_q1)) return rc;
@@ -2100,7 +2185,7 @@ static int jacobi(ttx_engine *h, int p, int q, double *X, double *V, double *sv,
     const int in_lds = lds <= 140 * 1024;
     static size_t a_j = 0;
     if (in_lds) { if (int rc = ensure_lds(reinterpret_cast<const void *>(k_jacobi_svd), lds, a_j)) return rc; }
-    hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(tt_threads("TTX_JAC_THREADS", 1024)), in_lds ? lds : 0, h->stream, p, q, X, V, sv, perm, info, 1, tol, rmax, in_lds);
+    hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(tt_threads("TTX_JAC_THREADS", 256)), in_lds ? lds : 0, h->stream, p, q, X, V, sv, perm, info, 1, tol, rmax, in_lds);
     return TTX_OK;
 }
 static int sumsq(ttx_engine *h, size_t n, const double *x, double *out_host)
@@ -2192,6 +2277,7 @@ static int svd_impl(ttx_engine *h, double tol, int rmax)
         HIPCHECK(hipMemcpyAsync(svh.data(), sv, sizeof(double) * mm, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(hipStreamSynchronize(h->stream));
         const int rr = inf[0];
+        if (getenv("TTX_JAC_TRACE")) fprintf(stderr, "svd core %d: %d x %d, %d Jacobi sweeps, rank %d\n", k, mm, mm, inf[1], rr);
         s2 = 0.0; for (int j = 0; j < rr; j++) s2 += svh[j] * svh[j];
         const double nrm = std::sqrt(s2);
         if (nrm != 0.0) lognrm += std::log(nrm);
@@ -2219,11 +2305,14 @@ static int svd_impl(ttx_engine *h, double tol, int rmax)
     return TTX_OK;
 }
 
+// (ort / svd change the train in place: on a multi-process engine that would mean redistributing cores whose ranks have changed;
+//  take a replica with ttx_replicate and work on that)
 extern "C" int ttx_ort(ttx_engine *h) { int rc = tt_prepare(h, "dtt_ort"); return rc ? rc : ort_impl(h); }
 extern "C" int ttx_svd(ttx_engine *h, double tol, int32_t rmax) { int rc = tt_prepare(h, "dtt_svd"); return rc ? rc : svd_impl(h, tol, rmax); }
 
 extern "C" int ttx_norm(ttx_engine *h, double tol, double *val)
 {
+    if (h && h->ran && h->W > 1) return with_replica(h, [&](ttx_engine *e) { return ttx_norm(e, tol, val); });
     int rc = tt_prepare(h, "dtt_norm");
     if (rc) return rc;
     if (!val) return fail(TTX_EINVAL, "dtt_norm: null result");
@@ -2255,6 +2344,10 @@ extern "C" int ttx_norm(ttx_engine *h, double tol, double *val)
 
 extern "C" int ttx_dot(ttx_engine *x, ttx_engine *y, double *val)
 {
+    if (x && y && x->ran && y->ran && (x->W > 1 || y->W > 1)) {      // replicas of whichever train is spread over processes
+        if (x->W > 1) return with_replica(x, [&](ttx_engine *ex) { return ttx_dot(ex, y, val); });
+        return with_replica(y, [&](ttx_engine *ey) { return ttx_dot(x, ey, val); });
+    }
     int rc = tt_prepare(x, "dtt_dot");
     if (rc || (rc = tt_prepare(y, "dtt_dot"))) return rc;
     if (!val) return fail(TTX_EINVAL, "dtt_dot: null result");
@@ -2285,8 +2378,53 @@ extern "C" int ttx_dot(ttx_engine *x, ttx_engine *y, double *val)
     return TTX_OK;
 }
 
+// ztt_quad of a MULTI-PROCESS job (lib/dmrgg.f90:1418-1523 is collective over mybonds): every process chains the matrices of the
+// cores it holds, the partial products travel by a SUM all-reduce into zero-padded slots, every process folds them in rank order
+static int zquad_multi(ttx_engine *h, int32_t nf, const double *w, double *out)
+{
+    if (!h->ran) return fail(TTX_ESTATE, "ztt_quad: run dtt_dmrgg first");
+    HIPCHECK(hipSetDevice(h->cfg.device));
+    const int d = h->d, RM = h->RM, W = h->W, nproc = h->cfg.nproc;
+    const size_t lds = sizeof(double) * 4 * (size_t)RM * RM;
+    if (lds > 160 * 1024) return fail(TTX_EINVAL, "ztt_quad: maxrank %d needs %zu bytes of LDS for the chain (limit 160 KB, maxrank <= 71)", RM, lds);
+    size_t sumn = 0;
+    for (int k = 1; k <= d; k++) sumn += h->n1[k];
+    auto lo_of = [&](int wr) { return h->own[(int)((long long)nproc * wr / W)]; };
+    auto hi_of = [&](int wr) { const int ge = (int)((long long)nproc * (wr + 1) / W); return ge == nproc ? d : h->own[ge] - 1; };
+    const int plo = lo_of(h->wrank), phi = hi_of(h->wrank);
+    std::vector<const double *> cp(d + 2, nullptr);
+    for (int k = plo; k <= phi; k++) cp[k] = core_dev(h, k);
+    std::vector<int> rr(h->rfinal.begin(), h->rfinal.end()), dims(2 * W);
+    for (int wr = 0; wr < W; wr++) { dims[2 * wr] = rr[lo_of(wr) - 1]; dims[2 * wr + 1] = rr[hi_of(wr)]; }
+    struct Tmp { std::vector<void *> p; ~Tmp() { for (void *q : p) (void)hipFree(q); } } tmp;
+    auto dalloc = [&](void **q, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(q, bytes); if (e == hipSuccess) tmp.p.push_back(*q); return e; };
+    double *dw, *dtq, *dout, *dpart; const double **dcp; int *dr, *ddims;
+    const size_t npart = (size_t)nf * W * 2 * RM * RM;
+    HIPCHECK(dalloc((void **)&dw, sizeof(double) * 2 * sumn * nf)); HIPCHECK(dalloc((void **)&dtq, sizeof(double) * (size_t)nf * (d + 1) * 2 * RM * RM));
+    HIPCHECK(dalloc((void **)&dout, sizeof(double) * 2 * nf)); HIPCHECK(dalloc((void **)&dcp, sizeof(double *) * (d + 2))); HIPCHECK(dalloc((void **)&dr, sizeof(int) * (d + 1)));
+    HIPCHECK(dalloc((void **)&dpart, sizeof(double) * npart)); HIPCHECK(dalloc((void **)&ddims, sizeof(int) * 2 * W));
+    HIPCHECK(hipMemcpy(dw, w, sizeof(double) * 2 * sumn * nf, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dcp, cp.data(), sizeof(double *) * (d + 2), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dr, rr.data(), sizeof(int) * (d + 1), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ddims, dims.data(), sizeof(int) * 2 * W, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemsetAsync(dpart, 0, sizeof(double) * npart, h->stream));
+    hipLaunchKernelGGL(k_zquad_build, dim3(d, nf), dim3(256), 0, h->stream, d, RM, h->NM, h->P.SS, h->P.n, (const int *)dr, (const double *const *)dcp, (const double *)dw, 2 * sumn, dtq);
+    static size_t a_zs = 0, a_zf = 0;
+    if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_zquad_chain_seg), lds, a_zs)) return rc_;
+    if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_zquad_fold), lds, a_zf)) return rc_;
+    hipLaunchKernelGGL(k_zquad_chain_seg, dim3(nf), dim3(256), lds, h->stream, d, RM, (const int *)dr, (const double *)dtq, plo, phi, h->wrank, W, dpart);
+    if (int rc_ = allreduce_big(h, dpart, npart)) return rc_;
+    hipLaunchKernelGGL(k_zquad_fold, dim3(nf), dim3(256), lds, h->stream, RM, W, (const int *)ddims, (const double *)dpart, dout);
+    HIPCHECK(hipMemcpyAsync(out, dout, sizeof(double) * 2 * nf, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipGetLastError());
+    if (h->cb_error) return fail(TTX_EHIP, "host transport: a sendrecv / allreduce callback failed");
+    return TTX_OK;
+}
+
 extern "C" int ttx_zquad(ttx_engine *h, int32_t nf, const double *w, double *out)
 {
+    if (h && h->W > 1) { if (nf < 1 || !w || !out) return fail(TTX_EINVAL, "ztt_quad: bad argument"); return zquad_multi(h, nf, w, out); }
     int rc = tt_prepare(h, "ztt_quad");
     if (rc) return rc;
     if (nf < 1 || !w || !out) return fail(TTX_EINVAL, "ztt_quad: bad argument");

@@ -105,19 +105,115 @@ __device__ __forceinline__ void qr_apply_reflector_cols(double *A, int m, int i,
     }
     __syncthreads();
 }
+// Householder QR of an LDS-RESIDENT m x n matrix (column-major, ld = m; dgeqr2 / dlarfg / dlarf, then dorg2r) with THREE workgroup
+// barriers per reflector of the factorisation and TWO per reflector of the generation (round 3; the phases used to be separated by
+// seven and five).  The kernels are chains of short phases, so the barriers were most of their time:
+//   * the squared norm that reflector i+1 needs is accumulated by the wave that updates column i+1 (no separate reduction phase);
+//   * the dot products w = tau A' v take v on the fly from column i (v_r = x_r * scale, the values dlarfg stores), while all threads
+//     write the same v into vsh for the update phase -- no phase of its own for v;
+//   * column i is rewritten (v below the diagonal, beta on it; in dorg2r: the column of Q) during the update phase, which reads vsh.
+// One wave per column in both phases.  After the first part the upper triangle holds R (emit(r, c, value) receives it, zeros
+// below the diagonal), after the second A holds the first min(m, n) columns of Q.  tauv: n doubles of LDS.
+__device__ __forceinline__ double jac_group_sum(double v, int tpp, int lane);
+template <class EMIT>
+__device__ __forceinline__ void qr_lds3(double *A, int m, int n, double *vsh, double *wsh, double *tauv, EMIT emit)
+{
+    __shared__ double s_xn2, s_tau, s_beta, s_scale;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6, mn = m < n ? m : n;
+    // wave sum on the DPP data path (a __shfl_xor of a double is two ds_bpermute round trips: twelve of them per dot product)
+    auto wsum = [&](double q) { return jac_group_sum(q, 64, lane); };
+    if (wv == 0) {
+        double q = 0.0;
+        for (int r = 1 + lane; r < m; r += 64) q += A[r] * A[r];
+        q = wsum(q);
+        if (lane == 0) s_xn2 = q;
+    }
+    __syncthreads();
+    for (int i = 0; i < mn; i++) {
+        double *x = A + i + (size_t)m * i;
+        const int len = m - i;
+        if (tid == 0) {
+            const double alpha = x[0], xn = sqrt(s_xn2);
+            if (xn == 0.0) { s_tau = 0.0; s_beta = alpha; s_scale = 0.0; }
+            else {
+                const double beta = -copysign(hypot(alpha, xn), alpha);
+                s_tau = (beta - alpha) / beta; s_beta = beta; s_scale = 1.0 / (alpha - beta);
+            }
+            tauv[i] = s_tau;
+        }
+        __syncthreads();                                                                        // (1) tau, beta, scale
+        const double sc = s_scale, tau = s_tau;
+        for (int r = tid; r < len; r += nt) vsh[r] = (r == 0) ? 1.0 : x[r] * sc;
+        for (int c = i + 1 + wv; c < n; c += nw) {
+            const double *cc = A + i + (size_t)m * c;
+            double q = 0.0;
+#pragma unroll 4
+            for (int r = lane; r < len; r += 64) q += ((r == 0) ? 1.0 : x[r] * sc) * cc[r];
+            q = wsum(q);
+            if (lane == 0) wsh[c] = q * tau;
+        }
+        __syncthreads();                                                                        // (2) w, vsh
+        for (int c = i + 1 + wv; c < n; c += nw) {
+            double *cc = A + i + (size_t)m * c;
+            const double wc = wsh[c];
+            double acc = 0.0;
+#pragma unroll 4
+            for (int r = lane; r < len; r += 64) { const double nv = cc[r] - vsh[r] * wc; cc[r] = nv; if (r >= 2) acc += nv * nv; }
+            if (c == i + 1) { acc = wsum(acc); if (lane == 0) s_xn2 = acc; }
+        }
+        for (int r = 1 + tid; r < len; r += nt) x[r] = vsh[r];
+        if (tid == 0) x[0] = s_beta;
+        __syncthreads();                                                                        // (3) trailing columns, column i, next norm
+    }
+    for (int t = tid; t < mn * n; t += nt) { const int r = t % mn, c = t / mn; emit(r, c, (r <= c) ? A[r + (size_t)m * c] : 0.0); }
+    __syncthreads();
+    for (int i = mn - 1; i >= 0; i--) {                                                         // dorg2r
+        double *x = A + i + (size_t)m * i;
+        const int len = m - i;
+        const double tau = tauv[i];
+        for (int r = tid; r < len; r += nt) vsh[r] = (r == 0) ? 1.0 : x[r];
+        for (int c = i + 1 + wv; c < mn; c += nw) {
+            const double *cc = A + i + (size_t)m * c;
+            double q = 0.0;
+#pragma unroll 4
+            for (int r = lane; r < len; r += 64) q += ((r == 0) ? 1.0 : x[r]) * cc[r];
+            q = wsum(q);
+            if (lane == 0) wsh[c] = q * tau;
+        }
+        __syncthreads();
+        for (int c = i + 1 + wv; c < mn; c += nw) {
+            double *cc = A + i + (size_t)m * c;
+            const double wc = wsh[c];
+#pragma unroll 4
+            for (int r = lane; r < len; r += 64) cc[r] -= vsh[r] * wc;
+        }
+        for (int r = tid; r < len; r += nt) x[r] = (r == 0) ? 1.0 - tau : -tau * vsh[r];
+        for (int r = tid; r < i; r += nt) A[r + (size_t)m * i] = 0.0;
+        __syncthreads();
+    }
+}
+
 // INLDS: the whole unfolding is staged in LDS (m n doubles <= the budget the host checked), factored there and written back
 template <bool INLDS>
 __global__ __launch_bounds__(1024) void k_qr(int m, int n, double *Ag, double *Rout, double *tau_out)
 {
     extern __shared__ __align__(16) double sm[];
     double *vsh = sm;                 // m
-    double *wsh = sm + m;             // n
-    double *A = INLDS ? sm + ((m + n + 1) & ~1) : Ag;
+    double *wsh = sm + m;             // n  (INLDS: + n for the taus)
+    double *A = INLDS ? sm + ((m + 2 * n + 1) & ~1) : Ag;
     __shared__ double red[16];
     __shared__ double part[16][QR_CH];
     __shared__ double s_tau, s_beta, s_scale;
     const int tid = threadIdx.x, nt = blockDim.x, mn = m < n ? m : n;
-    if (INLDS) { for (size_t x = tid; x < (size_t)m * n; x += nt) A[x] = Ag[x]; __syncthreads(); }
+    if (INLDS) {
+        for (size_t x = tid; x < (size_t)m * n; x += nt) A[x] = Ag[x];
+        __syncthreads();
+        double *tauv = wsh + n;                          // (the host sizes the LDS for m + 2 n + 4 doubles ahead of the matrix)
+        qr_lds3(A, m, n, vsh, wsh, tauv, [&](int r, int c, double v) { Rout[r + (size_t)mn * c] = v; });
+        for (int x = tid; x < mn; x += nt) tau_out[x] = tauv[x];
+        for (size_t x = tid; x < (size_t)m * mn; x += nt) Ag[x] = A[x];
+        return;
+    }
     for (int i = 0; i < mn; i++) {
         double *x = A + i + (size_t)m * i;
         const int len = m - i;
@@ -177,46 +273,10 @@ __global__ __launch_bounds__(1024) void k_qr_panel(int rows, int n, int rbs, con
     double *wsh = sm + rbs;           // n
     double *tauv = wsh + n;           // n
     double *A = sm + ((rbs + 2 * n + 1) & ~1);
-    __shared__ double red[16];
-    __shared__ double s_tau, s_beta, s_scale;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (size_t x = tid; x < (size_t)m * n; x += nt) { const int r = (int)(x % m), c = (int)(x / m); A[x] = M[r0 + r + (size_t)rows * c]; }
     __syncthreads();
-    for (int i = 0; i < n; i++) {
-        double *x = A + i + (size_t)m * i;
-        const int len = m - i;
-        double q = 0.0;
-        for (int r = 1 + tid; r < len; r += nt) q += x[r] * x[r];
-        const double xn2 = tt_block_sum(q, red);
-        if (tid == 0) {
-            const double alpha = x[0], xn = sqrt(xn2);
-            if (xn == 0.0) { s_tau = 0.0; s_beta = alpha; s_scale = 0.0; }
-            else {
-                const double beta = -copysign(hypot(alpha, xn), alpha);
-                s_tau = (beta - alpha) / beta; s_beta = beta; s_scale = 1.0 / (alpha - beta);
-            }
-            tauv[i] = s_tau;
-        }
-        __syncthreads();
-        for (int r = tid; r < len; r += nt) { double v = (r == 0) ? 1.0 : x[r] * s_scale; vsh[r] = v; if (r > 0) x[r] = v; }
-        __syncthreads();
-        if (tid == 0) x[0] = s_beta;
-        qr_apply_reflector_cols(A, m, i, len, i + 1, n, s_tau, vsh, wsh);
-    }
-    __syncthreads();
-    for (int x = tid; x < n * n; x += nt) { const int r = x % n, c = x / n; Rst[(size_t)p * n + r + (size_t)ldr * c] = (r <= c) ? A[r + (size_t)m * c] : 0.0; }
-    __syncthreads();
-    for (int i = n - 1; i >= 0; i--) {                     // dorg2r
-        double *x = A + i + (size_t)m * i;
-        const int len = m - i;
-        const double tau = tauv[i];
-        for (int r = tid; r < len; r += nt) vsh[r] = (r == 0) ? 1.0 : x[r];
-        __syncthreads();
-        qr_apply_reflector_cols(A, m, i, len, i + 1, n, tau, vsh, wsh);
-        for (int r = tid; r < len; r += nt) x[r] = (r == 0) ? 1.0 - tau : -tau * vsh[r];
-        for (int r = tid; r < i; r += nt) A[r + (size_t)m * i] = 0.0;
-        __syncthreads();
-    }
+    qr_lds3(A, m, n, vsh, wsh, tauv, [&](int r, int c, double v) { Rst[(size_t)p * n + r + (size_t)ldr * c] = v; });
     for (size_t x = tid; x < (size_t)m * n; x += nt) { const int r = (int)(x % m), c = (int)(x / m); Qout[r0 + r + (size_t)rows * c] = A[x]; }
 }
 __host__ __device__ inline size_t qr_panel_lds_doubles(int rbs, int n) { return (size_t)((rbs + 2 * n + 1) & ~1) + (size_t)rbs * n; }
@@ -306,6 +366,10 @@ __global__ void k_scal_core_acc(double *core, int r0, int n, int r1, int RM, siz
         core[i + (size_t)RM * j + SS * s] *= a;
     }
 }
+__global__ void k_fill_const(size_t n, double *x, double a)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = a;
+}
 __global__ void k_scal(size_t n, double *x, double a)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= a;
@@ -365,6 +429,9 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *Xg, d
     // threads per pair: a power of two <= 64 so that a pair never straddles a wave
     int t2 = 1; while (t2 * 2 <= tpp) t2 *= 2; tpp = t2;
     const int pairs_per_pass = nt / tpp;
+    // columns count as orthogonal at sqrt(p) eps (the criterion of LAPACK's one-sided Jacobi, dgesvj); a threshold BELOW eps (1e-16,
+    // round 2) is met only by chance: 2 of the 62 cores of the D_64 train ran all 60 sweeps, the others 6-7
+    const double jtol = 2.220446049250313e-16 * sqrt((double)p);
     int sweeps = 0;
     for (int sweep = 0; sweep < 60; sweep++) {
         if (tid == 0) s_rot = 0;
@@ -382,7 +449,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *Xg, d
                         for (int i = sub; i < p; i += tpp) { double u = xa[i], w = xb[i]; al += u * u; be += w * w; ga += u * w; }
                         if (tpp >= 16) { al = jac_group_sum(al, tpp, tid & 63); be = jac_group_sum(be, tpp, tid & 63); ga = jac_group_sum(ga, tpp, tid & 63); }
                         else for (int o = tpp >> 1; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
-                        if (!(fabs(ga) <= 1e-16 * sqrt(al * be) || ga == 0.0)) {
+                        if (!(fabs(ga) <= jtol * sqrt(al * be) || ga == 0.0)) {
                             if (sub == 0) atomicAdd(&s_rot, 1);
                             const double zeta = (be - al) / (2.0 * ga);
                             const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -458,6 +525,7 @@ __global__ __launch_bounds__(256) void k_zquad_build(int d, int RM, int NM, size
                                                      const double *w, size_t wstride, double *tq)
 {
     const int p = blockIdx.x + 1, f = blockIdx.y;
+    if (!cores[p]) return;                           // a core of another process (multi-process job: every process builds its own)
     const int r0 = r[p - 1], r1 = r[p], n = n1[p];
     size_t off = 0;
     for (int c = 1; c < p; c++) off += n1[c];
@@ -488,6 +556,63 @@ __global__ __launch_bounds__(256) void k_zquad_chain(int d, int RM, const int *r
             const int i = x % mym, j = x / mym;
             double cr = 0.0, ci = 0.0;
             for (int l = 0; l < r0; l++) {          // c += temp * a, temp = curr(l,j), a = prev(i,l)
+                const double br = tr[l + RM * j], bi = ti[l + RM * j], ar = pr[i + RM * l], ai = pi[i + RM * l];
+                cr = cr + (br * ar - bi * ai); ci = ci + (br * ai + bi * ar);
+            }
+            nr[i + RM * j] = cr; ni[i + RM * j] = ci;
+        }
+        __syncthreads();
+        double *t = pr; pr = nr; nr = t; t = pi; pi = ni; ni = t;
+    }
+    if (tid == 0) { out[2 * f] = pr[0]; out[2 * f + 1] = pi[0]; }
+}
+
+// ztt_quad on a multi-process job (lib/dmrgg.f90:1418-1523 with mybonds: every rank multiplies the matrices of its own cores, the
+// partial products are combined over the ranks): the chain over the cores [plo, phi] of THIS process, result (r[plo-1] x r[phi],
+// re / im planes) into slot `slot` of part: [nf][nslots][2][RM*RM]; then k_zquad_fold multiplies the slots in rank order.
+__global__ __launch_bounds__(256) void k_zquad_chain_seg(int d, int RM, const int *r, const double *tq, int plo, int phi, int slot, int nslots, double *part)
+{
+    extern __shared__ __align__(16) double sh[];     // 4 * RM*RM : prev(re,im), next(re,im)
+    const int f = blockIdx.x, tid = threadIdx.x, mym = r[plo - 1];
+    double *pr = sh, *pi = sh + RM * RM, *nr = pi + RM * RM, *ni = nr + RM * RM;
+    const double *t1 = tq + (((size_t)f * (d + 1) + plo) * 2) * RM * RM;
+    for (int x = tid; x < mym * r[plo]; x += blockDim.x) { pr[(x % mym) + RM * (x / mym)] = t1[(x % mym) + RM * (x / mym)]; pi[(x % mym) + RM * (x / mym)] = t1[(size_t)RM * RM + (x % mym) + RM * (x / mym)]; }
+    __syncthreads();
+    for (int p = plo + 1; p <= phi; p++) {
+        const double *tr = tq + (((size_t)f * (d + 1) + p) * 2) * RM * RM, *ti = tr + (size_t)RM * RM;
+        const int r0 = r[p - 1], r1 = r[p];
+        for (int x = tid; x < mym * r1; x += blockDim.x) {
+            const int i = x % mym, j = x / mym;
+            double cr = 0.0, ci = 0.0;
+            for (int l = 0; l < r0; l++) {
+                const double br = tr[l + RM * j], bi = ti[l + RM * j], ar = pr[i + RM * l], ai = pi[i + RM * l];
+                cr = cr + (br * ar - bi * ai); ci = ci + (br * ai + bi * ar);
+            }
+            nr[i + RM * j] = cr; ni[i + RM * j] = ci;
+        }
+        __syncthreads();
+        double *t = pr; pr = nr; nr = t; t = pi; pi = ni; ni = t;
+    }
+    double *o = part + (((size_t)f * nslots + slot) * 2) * RM * RM;
+    const int myn = r[phi];
+    for (int x = tid; x < mym * myn; x += blockDim.x) { o[(x % mym) + RM * (x / mym)] = pr[(x % mym) + RM * (x / mym)]; o[(size_t)RM * RM + (x % mym) + RM * (x / mym)] = pi[(x % mym) + RM * (x / mym)]; }
+}
+// product of the slots in rank order; dims[2 s], dims[2 s + 1]: rows / columns of slot s; out[2 f], out[2 f + 1]
+__global__ __launch_bounds__(256) void k_zquad_fold(int RM, int nslots, const int *dims, const double *part, double *out)
+{
+    extern __shared__ __align__(16) double sh[];
+    const int f = blockIdx.x, tid = threadIdx.x, mym = dims[0];
+    double *pr = sh, *pi = sh + RM * RM, *nr = pi + RM * RM, *ni = nr + RM * RM;
+    const double *t1 = part + (((size_t)f * nslots) * 2) * RM * RM;
+    for (int x = tid; x < mym * dims[1]; x += blockDim.x) { pr[(x % mym) + RM * (x / mym)] = t1[(x % mym) + RM * (x / mym)]; pi[(x % mym) + RM * (x / mym)] = t1[(size_t)RM * RM + (x % mym) + RM * (x / mym)]; }
+    __syncthreads();
+    for (int s = 1; s < nslots; s++) {
+        const double *tr = part + (((size_t)f * nslots + s) * 2) * RM * RM, *ti = tr + (size_t)RM * RM;
+        const int r0 = dims[2 * s], r1 = dims[2 * s + 1];
+        for (int x = tid; x < mym * r1; x += blockDim.x) {
+            const int i = x % mym, j = x / mym;
+            double cr = 0.0, ci = 0.0;
+            for (int l = 0; l < r0; l++) {
                 const double br = tr[l + RM * j], bi = ti[l + RM * j], ar = pr[i + RM * l], ai = pi[i + RM * l];
                 cr = cr + (br * ar - bi * ai); ci = ci + (br * ai + bi * ar);
             }

@@ -253,6 +253,14 @@ class TTCross:
         _check(L.ttx_read_hdf5(ctypes.byref(h), os.fsencode(path), int(device)))
         return cls._adopt(h)
 
+    def replicate(self):
+        """The train of a multi-process job gathered onto this process as a new single-process engine (collective; include/ttx.h)."""
+        L = load_library()
+        L.ttx_replicate.argtypes = [c_void_p, POINTER(c_void_p)]
+        h = c_void_p()
+        _check(L.ttx_replicate(self._h, ctypes.byref(h)))
+        return TTCross._adopt(h)
+
     def write(self, path):
         """dtt_write (lib/ttio.f90:29-108): the resident train in the reference's stream format."""
         _check(load_library().ttx_write(self._h, os.fsencode(path)))
