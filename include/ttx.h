@@ -110,7 +110,7 @@ int ttx_comm_init_shm(ttx_engine *h, const char *name);
  * (TTX_HOST_THREADS, else OMP_NUM_THREADS, else the hardware; `fun` must be thread-safe, as under the reference's
  * OpenMP loops), and the kernel continues with the values.  par is passed through untouched (may be NULL: the
  * reference's `par` is optional).  The sweep logic, pivot search and factor updates stay on the device; results are
- * those of the reference for the same `fun`.  pivoting = -1 is not available in this mode. */
+ * those of the reference for the same `fun`.  With pivoting = -1 the superblock goes to the host one column (k,q) at a time. */
 typedef double (*ttx_host_fun)(const int32_t *m, const int32_t *ind, const int32_t *n, const double *par);
 /* LIFETIME: the engine keeps the two pointers, it does not copy par.  They must stay valid for every later call that evaluates
  * (ttx_run, ttx_accchk); a caller whose par may move or die calls ttx_set_integrand_host again before such a call (the

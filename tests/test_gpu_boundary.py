@@ -36,7 +36,9 @@ def _user_setup(d, n):
     return dict(n=[n] * d, par=par, quad=[par[n:].copy()] * d, acc=500 * D.EPS)
 
 
-@pytest.mark.parametrize("d,n,r,piv,nproc", [(5, 17, 10, 2, 1), (6, 13, 8, 1, 3), (4, 9, 6, 0, 1), (8, 11, 7, 3, 2)])
+@pytest.mark.parametrize("d,n,r,piv,nproc", [(5, 17, 10, 2, 1), (6, 13, 8, 1, 3), (4, 9, 6, 0, 1), (8, 11, 7, 3, 2),
+                                             # full pivoting with the user's fun (lib/dmrgg.f90:341-408): one superblock column per launch pair
+                                             (4, 7, 5, -1, 1), (5, 5, 4, -1, 2)])
 def test_host_callback_bit_exact_vs_oracle(userfun, d, n, r, piv, nproc):
     """An integrand that is not built in: the engine asks the host for every fiber (ttx_set_integrand_host), the oracle
     calls the same C function -- tapes, evaluation counts, per-sweep values, cores and integral must be identical."""
@@ -69,9 +71,7 @@ def test_nan_integrand_neither_faults_nor_hangs(userfun, name, piv, nproc):
     x, w = D.lgwt(n)
     par = np.concatenate([0.5 * (x + 1.0), 0.5 * w])
     quad = [par[n:].copy()] * d
-    tt = E.TTCross([n] * d, E.TTX_FUN_HOST, [], r, pivoting=piv, accuracy=500 * D.EPS, quad=quad, nproc=nproc) if piv >= 0 else None
-    if tt is None:
-        pytest.skip("pivoting = -1 is not available with a host-evaluated fun")
+    tt = E.TTCross([n] * d, E.TTX_FUN_HOST, [], r, pivoting=piv, accuracy=500 * D.EPS, quad=quad, nproc=nproc)
     tt.set_integrand_host(addr, par).run()
     tp = tt.tapes()
     assert tp.shape[0] >= 1
@@ -133,8 +133,6 @@ def test_host_callback_needs_the_function():
     tt = E.TTCross(s["n"], E.TTX_FUN_HOST, [], 6, pivoting=1, accuracy=s["acc"])
     with pytest.raises(E.TTXError, match="ttx_set_integrand_host"):
         tt.run()
-    with pytest.raises(E.TTXError, match="pivoting = -1"):
-        E.TTCross(s["n"], E.TTX_FUN_HOST, [], 6, pivoting=-1)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])

@@ -156,6 +156,7 @@ struct DevProb {
     // hreq[slot] and stops before any side effect; the host calls `fun`; pass 2 (hostpass = 2) reads hval[slot].
     // All three arrays live in pinned host memory; a group's slots are [g*HS, (g+1)*HS).
     int hostpass, HS;
+    int zbase;                     // full pivoting with a host integrand: first superblock column (k,q) of this launch (one column per launch)
     short *hidx;
     double *hval;
     unsigned char *hreq;

@@ -313,7 +313,6 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     if (cfg->fun_id != TTX_FUN_HOST && cfg->fun_id != 0)
         for (int k = 1; k < cfg->d; k++)
             if (cfg->n[k] > cfg->n[0]) return fail(TTX_EINVAL, "ttx_create: mode %d has %d points, more than the first mode (%d): the built-in integrands index par by n(1)", k + 1, cfg->n[k], cfg->n[0]);
-    if (cfg->fun_id == TTX_FUN_HOST && cfg->pivoting < 0) return fail(TTX_EINVAL, "ttx_create: pivoting = -1 is not available with a host integrand");
     if (cfg->fun_id == TTX_FUN_HOST && cfg->d > 2048) return fail(TTX_EINVAL, "ttx_create: host integrand: at most 2048 dimensions (tt_size)");
     const int W = cfg->world_size < 1 ? 1 : cfg->world_size;
     const int nproc = std::max(cfg->nproc < 1 ? 1 : cfg->nproc, 1);
@@ -1381,12 +1380,27 @@ static int run_impl(ttx_engine *h)
                     hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 4, fastk ? 0 : h->half_vals);
                     hipLaunchKernelGGL(k_full_gemm_argmax, dim3(gx, gx, G), dim3(256), 0, st, P);
                     hipLaunchKernelGGL(k_full_resolve2, dim3(G), dim3(256), 0, st, P, gx, gx);
+                } else if (FUN == FUN_HOST) {
+                    // the user's `fun` with full pivoting (:341-408 works with any fun): one superblock column (k,q) per launch pair --
+                    // pass 1 hands the column's multi-indices to the host, pass 2 takes the values, residual and partial arg-max; the
+                    // ranks are at most it_ + 1 in sweep it_, columns beyond n2 r2 return at once
+                    const int zmax = h->NM * std::min((int)h->RM, it_ + 1);
+                    for (int z = 0; z < zmax; z++) {
+                        DevProb Q = P;
+                        Q.zbase = z;
+                        Q.hostpass = 1;
+                        hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, 1), dim3(TTX_BLK), h->lds_half, st, Q, 0, dir, 3, 0);
+                        if (int rc_ = host_eval(h)) return rc_;
+                        Q.hostpass = 2;
+                        hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, 1), dim3(TTX_BLK), h->lds_half, st, Q, 0, dir, 3, 0);
+                    }
+                    hipLaunchKernelGGL(k_full_resolve, dim3(G), dim3(256), 0, st, P);
                 } else {
                 hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G, h->NM * h->RM), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 3, fastk ? 0 : h->half_vals);
                 hipLaunchKernelGGL(k_full_resolve, dim3(G), dim3(256), 0, st, P);
                 }
-                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 0, dir, 2, fastk ? 0 : h->half_vals);
-                hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, P, 1, dir, 2, fastk ? 0 : h->half_vals);
+                if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, Q, 0, dir, 2, fastk ? 0 : h->half_vals); })) return rc_;
+                if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_halfstep<FUN>, dim3(nfb, G), dim3(TTX_BLK), h->lds_half, st, Q, 1, dir, 2, fastk ? 0 : h->half_vals); })) return rc_;
             }
             { KScope ks(h, TTX_K_ACCEPT); hipLaunchKernelGGL(k_accept, dim3(2 * nfb + 2 * h->NM + 1, G), dim3(TTX_BLK), lds_acc, st, P, h->H, nfb); }
         }

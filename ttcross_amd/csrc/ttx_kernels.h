@@ -1281,10 +1281,11 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     STAMP_DECL;
     if (tid == 0) {
         cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]);
-        if (mode == 3 || mode == 4) { cur.kk = (int)blockIdx.z % cur.n2 + 1; cur.qq = (int)blockIdx.z / cur.n2 + 1; }   // :356-369 column (k,q)
+        if (mode == 3 || mode == 4) { cur.kk = ((int)blockIdx.z + P.zbase) % cur.n2 + 1; cur.qq = ((int)blockIdx.z + P.zbase) / cur.n2 + 1; }   // :356-369 column (k,q)
     }
     __syncthreads();
-    if (mode == 3 || mode == 4) { if (!cur.active || (int)blockIdx.z >= cur.n2 * cur.r2) return; }
+    const int zcol = (int)blockIdx.z + P.zbase;
+    if (mode == 3 || mode == 4) { if (!cur.active || zcol >= cur.n2 * cur.r2) return; }
     else if (!cur.active || cur.done) { if (blockIdx.x == 0 && tid == 0) gs.S[h + 1] = cur; return; }
     STAMP(gs, 1);   // 0: resolve
     const bool iscol = (mode == 3 || mode == 4) ? true : (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
@@ -1428,7 +1429,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             else       { sx.pa = fxs; sx.A = p; sx.self = u + 1; sx.pb = vt + (size_t)v * VS; }
             a = eval_src3<FUN, true>(P, par, sx, (long)g * P.HS + t);         // :520-526 / :553-559
         }
-        if (mode == 4) P.sb[(size_t)g * ((size_t)P.RM * P.NM) * ((size_t)P.RM * P.NM) + (size_t)nf * blockIdx.z + t] = a;   // superblock column (k,q)
+        if (mode == 4) P.sb[(size_t)g * ((size_t)P.RM * P.NM) * ((size_t)P.RM * P.NM) + (size_t)nf * zcol + t] = a;   // superblock column (k,q)
         else if (mode != 3) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
     }
     STAMP(gs, 1);   // 2: eval
@@ -1460,13 +1461,13 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
         if (tid == 0) {
             Partial pr; pr.absmax = ab; pr.val = b; pr.idx = bi; pr.pad = 0;
             if (mode == 3) {   // superblock linear index ijkq = t + r0*n1*(column), :388-394
-                if (bi != INT_MAX) pr.idx = bi + r0 * n1 * (int)blockIdx.z;
-                P.pfull[((size_t)g * P.NM * P.RM + blockIdx.z) * P.nfb + blockIdx.x] = pr;
+                if (bi != INT_MAX) pr.idx = bi + r0 * n1 * zcol;
+                P.pfull[((size_t)g * P.NM * P.RM + zcol) * P.nfb + blockIdx.x] = pr;
             } else gs.Pt[h & 1][blockIdx.x] = pr;
         }
     }
     if (mode == 3 || mode == 4) {
-        if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) gs.neval += (long long)r0 * n1 * n2 * r2;   // :372
+        if (blockIdx.x == 0 && zcol == 0 && tid == 0 && P.hostpass != 1) gs.neval += (long long)r0 * n1 * n2 * r2;   // :372
         return;
     }
     if (blockIdx.x == 0 && tid == 0) {
