@@ -44,7 +44,8 @@ def test_fast_point_evaluator_vs_exact(kind, m, n):
 
 def test_fast_is_effective_only_where_an_evaluator_exists():
     s = D.ising_setup("c", 8, 17)
-    assert _run(s, 6, 2, 1, "fast").arith == "exact"                       # Ising C: O(d) already
+    tc = _run(s, 6, 2, 1, "fast")
+    assert tc.arith == ("fast" if tc.sweep_path() == "cluster" else "exact")   # Ising C: the closed form lives in the cluster kernel
     assert _run(D.box_setup("stdnorm", 4, 17), 6, 2, 1, "fast").arith == "exact"
     assert _run(D.ising_setup("d", 8, 17), 6, 2, 1, "fast").arith == "fast"
     assert _run(D.ising_setup("e", 8, 17), 6, 2, 1, None).arith == "exact"  # default
@@ -85,6 +86,33 @@ def test_fast_ising_tracks_exact_mode(kind, m, n, r, piv, nproc):
     acc = b.accchk(1500) if nproc == 1 else None
     if acc is not None and r >= 10 and piv > 0:
         assert acc["einf"] <= max(1e-5 * acc["ainf"], 50 * a.accchk(1500)["einf"])
+
+
+FAST_C = [(6, 33, 20, 2, 1), (16, 51, 32, 2, 8), (64, 51, 32, 2, 8), (8, 25, 12, 3, 2), (5, 17, 8, 0, 1), (21, 17, 33, 3, 3), (64, 51, 32, 2, 5)]
+
+
+@pytest.mark.parametrize("m,n,r,piv,nproc", FAST_C, ids=[f"c{c[0]}_n{c[1]}_r{c[2]}_p{c[3]}_np{c[4]}" for c in FAST_C])
+def test_fast_ising_c_tracks_exact_mode(m, n, r, piv, nproc):
+    """Ising C in fast mode: inside the cluster kernel an element is a closed form of its two free nodes (the running sums are
+    affine in their start state; f_ising_cfast) instead of a dependent chain of 2 m operations.  Against the exact mode: the same
+    number of sweeps, the same pivots over the leading sweeps, values to 1e-11, evaluation counts to 2 %, the integral to 1e-12
+    (and the analytic value as well as the exact mode reaches it)."""
+    s = D.ising_setup("c", m, n)
+    a, b = _run(s, r, piv, nproc, "exact"), _run(s, r, piv, nproc, "fast")
+    if b.sweep_path() != "cluster":
+        pytest.skip("the closed form lives in the cluster kernel")
+    assert b.arith == "fast" and a.arith == "exact"
+    ra, rb = a.sweeps(), b.sweeps()
+    assert len(ra) == len(rb)
+    lead = min(4, len(ra) - 1)
+    assert np.array_equal(a.tapes()[:lead, 1:a.d], b.tapes()[:lead, 1:a.d]), "pivots of the leading sweeps differ"
+    for x, y in zip(ra[:lead + 1], rb[:lead + 1]):
+        assert abs(x["val"] - y["val"]) <= 1e-11 * abs(x["val"]), f"sweep {x['it']}"
+        assert abs(x["neval"] - y["neval"]) <= 0.02 * x["neval"]
+    va, vb = a.quad(s["quad"]), b.quad(s["quad"])
+    assert abs(va - vb) <= 1e-12 * abs(va)
+    if s["tru"]:
+        assert abs(1 - vb / s["tru"]) <= 2 * abs(1 - va / s["tru"]) + 1e-13
 
 
 FAST_MVN = [(6, 33, 12, 2, 1), (9, 17, 10, 3, 2), (5, 9, 9, 2, 1), (32, 33, 20, 2, 4), (12, 17, 8, 0, 3), (4, 11, 6, -1, 1)]

@@ -94,6 +94,19 @@ __device__ __forceinline__ void wave_argmax2(double &a, double &v, int &idx)
     else { idx = kmin >> 1; v = (kmin & 1) ? -amx : amx; }
 }
 
+// TTX_ARITH=fast for Ising C: the two running sums of test_crs_ising.f90:197-204 are affine in their start state, so with the
+// prefix states of the pivot rows (pv, pvk after the right row; pw, pwk after the left row), the sums SL / SR of the partial
+// products that start at the bond and the weight products WL / WR an element is a closed form of its two free nodes:
+//   v = pv + pvk xk (1 + xj (1 + SL)),   w = pw + pwk xj (1 + xk (1 + SR)),   f = 2 / (v w) * WL wj wk WR
+// -- fifteen operations instead of a dependent chain of 2 m fed from LDS; equal to the exact value to rounding.
+__device__ __forceinline__ double f_ising_cfast(double xj, double wj, double xk, double wk, double pv, double pvk, double pw, double pwk,
+                                                double SL, double WL, double SR, double WR)
+{
+    const double v = pv + pvk * xk * (1.0 + xj * (1.0 + SL));
+    const double w = pw + pwk * xj * (1.0 + xk * (1.0 + SR));
+    return 2.0 / (v * w) * ((WL * wj) * (wk * WR));
+}
+
 // 16-byte records exchanged between the blocks of a cluster: one store / one load instruction each, agent scope
 // (sc1: the store goes through to the point of coherence, the load does not hit in the vector L1)
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -157,6 +170,10 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
     __shared__ ttx_cdfseg segc[TTX_TABSEG], segr[TTX_TABSEG];
     __shared__ double sha[8], shv[8], shm[8]; __shared__ int shi[8];
     __shared__ double pLw[64], pLk[64], pRv[64], pRk[64];   // prefix states of the two running sums per left / right row
+    // TTX_ARITH=fast: per pivot row the sum of the partial products that start at the bond (left: descending, right: ascending) and
+    // the product of its weights -- with them the integrand is a closed form of the two free nodes (f_ising_cfast)
+    __shared__ double fSL[64], fWL[64], fSR[64], fWR[64];
+    const bool cfast = P.arith != 0;
     // results of the rook loop, handed from wave 0 to the waves of the workgroup that own no fiber element at the current ranks
     __shared__ struct { int ii, jj, kk, qq, hcount, rc_k, rc_q, rr_i, rr_j; double pivot, amax, bytes_half; long long neval, n_resid; } s_rook;
     const int bid = blockIdx.x;
@@ -340,12 +357,28 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             auto wstep = [&](double xv) { wk = wk * xv; w = w + wk; };
             chain8v<false>(XL + (size_t)tid * RS, p - 1, wstep);
             pLw[tid] = w; pLk[tid] = wk;
+            if (cfast) {
+                double sk = 1.0, ss = 0.0, ww = 1.0;
+                auto sstep = [&](double xv) { sk = sk * xv; ss = ss + sk; };
+                auto pstep = [&](double xv) { ww = ww * xv; };
+                chain8v<true>(XL + (size_t)tid * RS, p - 1, sstep);
+                chain8v<false>(XL + (size_t)tid * RS + VS, p - 1, pstep);
+                fSL[tid] = ss; fWL[tid] = ww;
+            }
         } else if (tid >= 64 && tid < 64 + r2) {       // descending sum over the right row (dims p+2..m)
             const int c = tid - 64;
             double v = 1.0, vk = 1.0;
             auto vstep = [&](double xv) { vk = vk * xv; v = v + vk; };
             chain8v<true>(XR + (size_t)c * RS, m - p - 1, vstep);
             pRv[c] = v; pRk[c] = vk;
+            if (cfast) {
+                double sk = 1.0, ss = 0.0, ww = 1.0;
+                auto sstep = [&](double xv) { sk = sk * xv; ss = ss + sk; };
+                auto pstep = [&](double xv) { ww = ww * xv; };
+                chain8v<false>(XR + (size_t)c * RS, m - p - 1, sstep);
+                chain8v<false>(XR + (size_t)c * RS + VS, m - p - 1, pstep);
+                fSR[c] = ss; fWR[c] = ww;
+            }
         }
         __syncthreads();
         CST(2);
@@ -359,7 +392,8 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
             const int i = (x - 1) % r0 + 1, j = (x - 1) / r0 + 1, k = (y - 1) % n2 + 1, q = (y - 1) / n2 + 1;
             lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
             const double *rl = XL + (size_t)(i - 1) * RS, *rq = XR + (size_t)(q - 1) * RS;
-            const double f = F_ISING_CL(m, p - 1, rl, rl + VS, par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], rq, rq + VS, pRv[q - 1], pRk[q - 1], pLw[i - 1], pLk[i - 1]);
+            const double f = cfast ? f_ising_cfast(par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], pRv[q - 1], pRk[q - 1], pLw[i - 1], pLk[i - 1], fSL[i - 1], fWL[i - 1], fSR[q - 1], fWR[q - 1])
+                                   : F_ISING_CL(m, p - 1, rl, rl + VS, par[j - 1], par[n1m + j - 1], par[k - 1], par[n1m + k - 1], rq, rq + VS, pRv[q - 1], pRk[q - 1], pLw[i - 1], pLk[i - 1]);
             ma = fmax(ma, fabs(f));
             CST(4);
             const double *c = Cp + (i - 1) + (size_t)RM * (j - 1), *w = Wq + (k - 1) + (size_t)NM * (q - 1);
@@ -435,7 +469,8 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                         for (int s = 0; s < TTX_CL_CF; s++) if (s < r1u) cf[s] = c[P.SS * s];
                     }
 #endif
-                    a = F_ISING_CL(m, p - 1, rl, rl + VS, par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], rq, rq + VS, pRv[qq - 1], pRk[qq - 1], pLw[i], pLk[i]);
+                    a = cfast ? f_ising_cfast(par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], pRv[qq - 1], pRk[qq - 1], pLw[i], pLk[i], fSL[i], fWL[i], fSR[qq - 1], fWR[qq - 1])
+                              : F_ISING_CL(m, p - 1, rl, rl + VS, par[j], par[n1m + j], par[kk - 1], par[n1m + kk - 1], rq, rq + VS, pRv[qq - 1], pRk[qq - 1], pLw[i], pLk[i]);
                     fib[u] = a;
                     if (resid) {
                         double b = a;
@@ -460,7 +495,8 @@ __global__ __launch_bounds__(CB) void k_sweep_cluster(DevProb P, int dir, int ns
                         for (int s = 0; s < TTX_CL_CF; s++) if (s < r1u) cf[s] = w[P.SW * s];
                     }
 #endif
-                    a = F_ISING_CL(m, p - 1, rl, rl + VS, par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], rq, rq + VS, pRv[q], pRk[q], pLw[ii - 1], pLk[ii - 1]);
+                    a = cfast ? f_ising_cfast(par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], pRv[q], pRk[q], pLw[ii - 1], pLk[ii - 1], fSL[ii - 1], fWL[ii - 1], fSR[q], fWR[q])
+                              : F_ISING_CL(m, p - 1, rl, rl + VS, par[jj - 1], par[n1m + jj - 1], par[k], par[n1m + k], rq, rq + VS, pRv[q], pRk[q], pLw[ii - 1], pLk[ii - 1]);
                     fib[u] = a;
                     if (resid) {
                         double tt = 0.0;

@@ -146,6 +146,7 @@ struct ttx_engine {
     int lot_wave = 0;                       // Ising D/E: lottery candidates and boundary corners by the row-wise wave evaluator (ttx_de.h)
     int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
     int fast_cap = 0;                       // TTX_ARITH=fast: rows of each decay table the lottery kernel keeps in LDS
+    bool want_fast = false;                 // fast arithmetic was asked for (ttx_config.arith / TTX_ARITH); P.arith says where it is effective
     int fused = 0;                      // whole-sweep kernel (ttx_fused.h) usable for this problem
     size_t lds_fused = 0;
     hipStream_t qstream = nullptr;      // forked per-sweep quadrature (single-process runs)
@@ -398,6 +399,7 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
             else if (v == "exact") want = (cfg->arith == TTX_ARITH_FAST);
             else { ttx_destroy(h); return fail(TTX_EINVAL, "TTX_ARITH must be exact or fast (got %s)", e); }
         }
+        h->want_fast = want && !nofun;
         bool unit = true;               // Ising: all nodes in [0,1] (every running product non-increasing: the cut at 2^-54 is valid)
         if (cfg->fun_id == TTX_FUN_ISING) for (int j = 0; j < cfg->n[0]; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) unit = false;
         P.arith = (want && !nofun && ((cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && unit) || cfg->fun_id == TTX_FUN_MVN)) ? 1 : 0;
@@ -608,6 +610,8 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         else if (want == "fused") { if (fused_ok) h->fused = 1; }
         else if (want == "auto") { if (cluster_ok) h->cluster = NB; else if (fused_ok && h->G == 1) h->fused = 1; }
         else if (want != "chain") { ttx_destroy(h); return fail(TTX_EINVAL, "TTX_SWEEP must be auto, chain, fused or cluster (got %s)", want.c_str()); }
+        // TTX_ARITH=fast for Ising C: a closed form inside the cluster kernel (f_ising_cfast); the other paths evaluate C exactly
+        if (h->cluster && h->want_fast && cfg->fun_id == TTX_FUN_ISING && P.ising_id == 1) P.arith = 1;
         if (h->cluster) {
             unsigned *ctr; ClPart *cp;
             rc = dev_alloc(h, &ctr, (size_t)h->G); if (rc) { ttx_destroy(h); return rc; }
@@ -1590,6 +1594,7 @@ extern "C" int ttx_run(ttx_engine *h)
                 (void)hipGetLastError();
                 *h->h_abort = 0;
                 h->cluster = 0; h->cluster_aborted = false; h->cluster_fallbacks++;
+                if (h->P.ising_id == 1) h->P.arith = 0;        // the closed form of Ising C lives in the cluster kernel only
                 for (int k = 0; k < TTX_K_NKINDS; k++) { h->k_launches[k] = 0; h->k_ms[k] = 0; h->k_bytes[k] = 0; }
                 rc = run_impl<FUN_ISING>(h);
             }
