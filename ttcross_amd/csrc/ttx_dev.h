@@ -89,6 +89,10 @@ struct DevProb {
     // mvn: Y = S d (row = dimension).  fDv [G][FD][RM] (mvn): the pivot's difference vector.  fPiv [G][FS][RM]: scalars per pivot.
     double *fNear[2], *fDv[2], *fPiv[2];
     int FD;
+    // fpersist (Ising D/E): the tables are kept PER BOND ([G][NC] slots each side) and maintained incrementally -- a new pivot's entry is
+    // derived from its parent's in O(cut length) when it is accepted (k_accept), entries of rank-1 starts and of the neighbours'
+    // boundary pivots are made from scratch; 0 (mvn): one table per group, rebuilt per bond step by k_fast_tables
+    int fpersist;
     const double *auxS;        // mvn, fast: (inv_cov + inv_cov') / 2, d x d
     int nprocs;                // global number of groups
     int has_quad;

@@ -405,9 +405,11 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         P.arith = (want && !nofun && ((cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && unit) || cfg->fun_id == TTX_FUN_MVN)) ? 1 : 0;
         if (P.arith) {
             P.FD = d + 1;
+            P.fpersist = (cfg->fun_id == TTX_FUN_ISING) ? 1 : 0;       // Ising D/E: tables per bond, maintained incrementally (ttx_fast.h)
+            const size_t slots = P.fpersist ? G * NC : G;
             for (int sd = 0; sd < 2; sd++) {
-                A_(dev_alloc(h, &P.fNear[sd], G * (size_t)P.FD * RM));
-                A_(dev_alloc(h, &P.fPiv[sd], G * (size_t)TTX_FS * RM));
+                A_(dev_alloc(h, &P.fNear[sd], slots * (size_t)P.FD * RM));
+                A_(dev_alloc(h, &P.fPiv[sd], slots * (size_t)TTX_FS * RM));
                 if (cfg->fun_id == TTX_FUN_MVN) A_(dev_alloc(h, &P.fDv[sd], G * (size_t)P.FD * RM));
             }
             if (cfg->fun_id == TTX_FUN_MVN) {
@@ -1251,7 +1253,7 @@ static int run_impl(ttx_engine *h)
         if (srows && (rc = ensure_lds(reinterpret_cast<const void *>(k_init_samples<FUN>), lds_s, a_samp))) return rc;
         if ((rc = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_init_samples<FUN>, dim3(G), dim3(256), srows ? lds_s : h->lds_par, st, Q, snum, nn, FUN == FUN_HOST ? 0 : srows, 0); }))) return rc;
         if ((rc = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_init_fibers<FUN>, dim3(h->NC, G), dim3(256), h->lds_par, st, Q); }))) return rc;
-        hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(k_init_factors, dim3(h->NC, G), dim3(256), (P.arith && P.fpersist) ? sizeof(double) * 4 * (d + 8) : 0, st, P);
         hipLaunchKernelGGL(k_init_final, dim3(G), dim3(256), 0, st, P);
     }
     // Single-process whole-sweep path: the first sweep kernel is enqueued right behind the initial cross, and the host
@@ -1318,7 +1320,7 @@ static int run_impl(ttx_engine *h)
                 hipLaunchKernelGGL(k_de_tables, dim3((2 * (d + 1) * h->RM + 255) / 256, G), dim3(256), 0, st, P, dir, pp);
             }
             const bool fastk = P.arith && (FUN == FUN_MVN || (FUN == FUN_ISING && P.ising_id != 1));
-            if (fastk) {    // TTX_ARITH=fast: per-pivot tables of this bond step (ttx_fast.h)
+            if (fastk && !P.fpersist) {    // TTX_ARITH=fast, mvn: per-pivot tables of this bond step (ttx_fast.h; Ising D/E keeps its tables per bond)
                 KScope ks(h, TTX_K_OTHER);
                 hipLaunchKernelGGL(k_fast_tables<FUN>, dim3(2 * h->RM, G), dim3(64), sizeof(double) * 2 * (d + 8), st, P, dir, pp);
             }
@@ -1419,7 +1421,7 @@ static int run_impl(ttx_engine *h)
                 if (int rc_ = xfer_neighbours(h)) return rc_;
                 if (int rc_ = allreduce_dev(h, P.redsend, P.redrecv, 4, 1)) return rc_;
             }
-            hipLaunchKernelGGL(k_exch_max_apply, dim3(G), dim3(256), 0, st, P, h->W > 1 ? 1 : 0, nproc > 1 ? 1 : 0);
+            hipLaunchKernelGGL(k_exch_max_apply, dim3(G), dim3(256), (P.arith && P.fpersist) ? sizeof(double) * 4 * (d + 8) : 0, st, P, h->W > 1 ? 1 : 0, nproc > 1 ? 1 : 0);
             if (nproc > 1) {
                 const size_t VSb = ((d + 7) & ~7) + 8;
                 const size_t lds_b = h->lds_par + 16 + sizeof(short) * 2 * VSb + sizeof(double) * (64 * 64 + 4) +
@@ -1468,7 +1470,7 @@ static int run_impl(ttx_engine *h)
         if (nproc > 1) {
             hipLaunchKernelGGL(k_exch_pack, dim3(G), dim3(256), 0, st, P);
             if (int rc_ = xfer_neighbours(h)) return rc_;
-            hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), 0, st, P);
+            hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), (P.arith && P.fpersist) ? sizeof(double) * 4 * (d + 8) : 0, st, P);
         }
         const size_t lds_f = sizeof(double) * ((size_t)h->RM * h->RM + 256 * (size_t)h->RM);
         const int fl = lds_f <= 150 * 1024 ? 1 : 0;

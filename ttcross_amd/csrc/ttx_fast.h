@@ -154,6 +154,82 @@ __device__ __forceinline__ double de_fast_point_wave(int id, int m, const double
 __device__ __forceinline__ bool fast_path(const DevProb &P, int FUN)
 { return P.arith && ((FUN == FUN_ISING && P.ising_id != 1) || FUN == FUN_MVN); }
 
+// base of the table rows a bond step at bond p works with: side 0 = left pivots of bond p-1, side 1 = right pivots of bond p+1
+// (slots as L_ptr / R_ptr: left tables of bonds first-1..last, right tables of bonds first..last+1)
+__device__ __forceinline__ size_t fast_slot(const DevProb &P, int side, int g, int bond, int first)
+{ return P.fpersist ? (size_t)g * P.NC + (size_t)(side == 0 ? bond - first + 1 : bond - first) : (size_t)g; }
+__device__ __forceinline__ double *fast_near(const DevProb &P, int side, int g, int bond, int first)
+{ return P.fNear[side] + fast_slot(P, side, g, bond, first) * (size_t)P.FD * P.RM; }
+__device__ __forceinline__ double *fast_piv(const DevProb &P, int side, int g, int bond, int first)
+{ return P.fPiv[side] + fast_slot(P, side, g, bond, first) * (size_t)TTX_FS * P.RM; }
+
+// Table entry of ONE pivot FROM SCRATCH by one wave (all 64 lanes call it).  xs / ws: node and weight values of the pivot's own
+// dims in natural order (len of them, LDS, visible to the wave); side 0: the bond lies behind the last dim, side 1: before the
+// first.  near / piv: the pivot's column of the tables (stride RM).
+__device__ __forceinline__ void fast_entry_scratch(const double *xs, const double *ws, int len, int side, double *near, double *piv, int RM, int lane)
+{
+    // uniform scans (every lane the same): the decay vector towards the bond with its sum, and the sum of the products that start
+    // at the chain's end.  Both stop at the cut: the products are non-increasing, a later term is below 2^-54 of a sum that is
+    // only ever added to 1.  The two full products (all nodes, all weights) are taken by the wave.
+    double dc = 1.0, S1 = 0.0, pq = 1.0, S2 = 0.0;
+    int cnt = 1;
+    if (lane == 0) near[0] = 1.0;
+    for (int t = 1; t <= len; t++) {
+        dc = dc * (side == 0 ? xs[len - t] : xs[t - 1]);          // the t dims nearest to the bond
+        if (dc <= TTX_FCUT) break;
+        S1 = S1 + dc;
+        cnt = t + 1;
+        if (lane == (t & 63)) near[(size_t)t * RM] = dc;
+    }
+    for (int t = 1; t <= len; t++) {
+        pq = pq * (side == 0 ? xs[t - 1] : xs[len - t]);          // left: prefix products from dim 1; right: suffix products from dim d
+        if (pq <= TTX_FCUT) break;
+        S2 = S2 + pq;
+    }
+    double W = 1.0, F = 1.0;
+    for (int k = lane; k < len; k += 64) { W = W * ws[k]; F = F * xs[k]; }
+    W = wave_prod(W); F = wave_prod(F);
+    // ranges inside the pivot's dims: lane = end position, walk the start towards smaller positions until the cut
+    double N = 1.0, D = 1.0;
+    for (int e = lane; e < len; e += 64) {
+        double u = 1.0;
+        for (int s = e; s >= 0; s--) {
+            u = u * xs[s];
+            if (u <= TTX_FCUT) break;
+            N = N * (1.0 - u); D = D * (1.0 + u);
+        }
+    }
+    N = wave_prod(N); D = wave_prod(D);
+    if (lane == 0) {
+        piv[FP_T * RM] = N / D; piv[FP_W * RM] = W; piv[FP_S * RM] = S1; piv[FP_P * RM] = S2;
+        piv[FP_F * RM] = F; piv[FP_N * RM] = (double)cnt;
+    }
+}
+// Table entry of a NEW pivot from its PARENT's by one wave: the new pivot is the parent's multi-index with one more dimension (node
+// x, weight w) on the bond's side.  Decay vector: near_c[t] = x near_p[t-1]; the new ranges are the ones that contain the new dim and
+// end at the bond (arguments near_c[t], t >= 1); sums and products are extended by one term.  O(cut length) instead of O(d L).
+__device__ __forceinline__ void fast_entry_child(const double *pnear, const double *ppiv, double x, double w, double *cnear, double *cpiv, int RM, int lane)
+{
+    const int cp = (int)ppiv[FP_N * RM];
+    double N = 1.0, D = 1.0, S1 = 0.0;
+    int cnt = 1;
+    if (lane == 0) cnear[0] = 1.0;
+    for (int t0 = 1; t0 <= cp; t0 += 64) {                        // child entries t = 1 .. cp come from parent entries t-1 = 0 .. cp-1
+        const int t = t0 + lane;
+        const double v = (t <= cp) ? x * pnear[(size_t)(t - 1) * RM] : 0.0;
+        const bool on = v > TTX_FCUT;
+        if (on) { cnear[(size_t)t * RM] = v; N = N * (1.0 - v); D = D * (1.0 + v); S1 = S1 + v; }
+        cnt += __popcll(__ballot(on));
+    }
+    N = wave_prod(N); D = wave_prod(D); S1 = wave_sum(S1);
+    if (lane == 0) {
+        const double F = ppiv[FP_F * RM] * x;
+        cpiv[FP_T * RM] = ppiv[FP_T * RM] * (N / D); cpiv[FP_W * RM] = ppiv[FP_W * RM] * w; cpiv[FP_S * RM] = S1;
+        cpiv[FP_P * RM] = ppiv[FP_P * RM] + (F > TTX_FCUT ? F : 0.0);
+        cpiv[FP_F * RM] = F; cpiv[FP_N * RM] = (double)cnt;
+    }
+}
+
 // value of the Ising D/E integrand from rho of the ranges through the free dimension(s) and the two pivots' table entries
 // (pL / pR point at the pivot's column of fPiv, stride RM): rho -> 2 rho^2 [b] w_1 ... w_m
 __device__ __forceinline__ double de_fast_value(int id, int RM, double rho, const double *pL, double xj, double wj, double xk, double wk, const double *pR)
@@ -166,12 +242,12 @@ __device__ __forceinline__ double de_fast_value(int id, int RM, double rho, cons
 
 // one lottery candidate (left pivot i | j | k | right pivot q), 0-based, by one thread.  sL / sR: LDS copies of the first `cap`
 // rows of the two near tables ([t][RM]); rows beyond come from global memory.
-__device__ __forceinline__ double de_fast_elem4(const DevProb &P, int g, int i, int j, int k, int q, const double *sL, const double *sR, int cap)
+__device__ __forceinline__ double de_fast_elem4(const DevProb &P, int g, int p, int first, int i, int j, int k, int q, const double *sL, const double *sR, int cap)
 {
     const int RM = P.RM;
     const double *nodes = P.par, *weights = P.par + P.n[1];
-    const double *nL = P.fNear[0] + (size_t)g * P.FD * RM + i, *nR = P.fNear[1] + (size_t)g * P.FD * RM + q;
-    const double *pL = P.fPiv[0] + (size_t)g * TTX_FS * RM + i, *pR = P.fPiv[1] + (size_t)g * TTX_FS * RM + q;
+    const double *nL = fast_near(P, 0, g, p - 1, first) + i, *nR = fast_near(P, 1, g, p + 1, first) + q;
+    const double *pL = fast_piv(P, 0, g, p - 1, first) + i, *pR = fast_piv(P, 1, g, p + 1, first) + q;
     const int cl = (int)pL[FP_N * RM], cr = (int)pR[FP_N * RM];
     const double xj = nodes[j], xk = nodes[k];
     double N = 1.0, D = 1.0;
@@ -257,7 +333,7 @@ __global__ __launch_bounds__(64) void k_fast_tables(DevProb P, int dir, int pp)
     if (c >= (side == 0 ? r[p - 1] : r[p + 1])) return;
     const int A = p - 1, B = m - p - 1, len = side == 0 ? A : B;
     const short *tab = side == 0 ? L_ptr(P, g, p - 1, first) : R_ptr(P, g, p + 1, first);
-    double *near = P.fNear[side] + (size_t)g * P.FD * RM, *piv = P.fPiv[side] + (size_t)g * TTX_FS * RM;
+    double *near = fast_near(P, side, g, side == 0 ? p - 1 : p + 1, first), *piv = fast_piv(P, side, g, side == 0 ? p - 1 : p + 1, first);
     double *xs = dyn, *ws = dyn + m + 8;
     if (FUN == FUN_MVN) {
         // dv = x - mu over the pivot's dims (0-based dim of entry k: k on the left, p+1+k on the right); Y = S dv; Q = dv' Y
@@ -281,40 +357,5 @@ __global__ __launch_bounds__(64) void k_fast_tables(DevProb P, int dir, int pp)
     const double *nodes = P.par - 1, *weights = P.par + P.n[1] - 1;
     for (int k = lane; k < len; k += 64) { const int ix = tab[(size_t)k * RM + c]; xs[k] = nodes[ix]; ws[k] = weights[ix]; }
     __syncthreads();
-    // uniform scans (every lane the same): the decay vector towards the bond with its sum, and the sum of the products that start
-    // at the chain's end.  Both stop at the cut: the products are non-increasing, a later term is below 2^-54 of a sum that is
-    // only ever added to 1.  The two full products (all nodes, all weights) are taken by the wave.
-    double dc = 1.0, S1 = 0.0, pq = 1.0, S2 = 0.0;
-    int cnt = 1;
-    if (lane == 0) near[c] = 1.0;
-    for (int t = 1; t <= len; t++) {
-        dc = dc * (side == 0 ? xs[len - t] : xs[t - 1]);          // the t dims nearest to the bond
-        if (dc <= TTX_FCUT) break;
-        S1 = S1 + dc;
-        cnt = t + 1;
-        if (lane == (t & 63)) near[(size_t)t * RM + c] = dc;
-    }
-    for (int t = 1; t <= len; t++) {
-        pq = pq * (side == 0 ? xs[t - 1] : xs[len - t]);          // left: prefix products from dim 1; right: suffix products from dim d
-        if (pq <= TTX_FCUT) break;
-        S2 = S2 + pq;
-    }
-    double W = 1.0, F = 1.0;
-    for (int k = lane; k < len; k += 64) { W = W * ws[k]; F = F * xs[k]; }
-    W = wave_prod(W); F = wave_prod(F);
-    // ranges inside the pivot's dims: lane = end position, walk the start towards smaller positions until the cut
-    double N = 1.0, D = 1.0;
-    for (int e = lane; e < len; e += 64) {
-        double u = 1.0;
-        for (int s = e; s >= 0; s--) {
-            u = u * xs[s];
-            if (u <= TTX_FCUT) break;
-            N = N * (1.0 - u); D = D * (1.0 + u);
-        }
-    }
-    N = wave_prod(N); D = wave_prod(D);
-    if (lane == 0) {
-        piv[FP_T * RM + c] = N / D; piv[FP_W * RM + c] = W; piv[FP_S * RM + c] = S1; piv[FP_P * RM + c] = S2;
-        piv[FP_F * RM + c] = F; piv[FP_N * RM + c] = (double)cnt;
-    }
+    fast_entry_scratch(xs, ws, len, side, near + c, piv + c, RM, lane);
 }

@@ -832,6 +832,19 @@ __global__ __launch_bounds__(256) void k_init_factors(DevProb P)
         short *Rt = R_ptr(P, g, s2, first);
         for (int x = tid; x < m - s2; x += blockDim.x) Rt[(size_t)x * P.RM] = (short)P.ind0[s2 + 1 + x];
         if (tid == 0 && blockIdx.x == 0) inv_ptr(P, g, first - 1, first)[0] = 1.0;   // :147
+        if (P.arith && P.fpersist) {
+            // TTX_ARITH=fast, Ising D/E: the table entries of the rank-1 start (pivot 0 of every bond) from scratch: wave 0 the left
+            // multi-index ind0[1..s] of bond s, wave 1 the right multi-index ind0[s2+1..m] of bond s2
+            extern __shared__ __align__(16) double dyn_i[];
+            const int wv_ = tid >> 6, lane_ = tid & 63;
+            if (wv_ < 2) {
+                double *xs = dyn_i + (size_t)wv_ * 2 * (m + 8), *ws = xs + m + 8;
+                const int len = wv_ == 0 ? s : m - s2, o0 = wv_ == 0 ? 1 : s2 + 1;
+                for (int k = lane_; k < len; k += 64) { const int ix = P.ind0[o0 + k]; xs[k] = P.par[ix - 1]; ws[k] = P.par[P.n[1] + ix - 1]; }
+                __builtin_amdgcn_wave_barrier();
+                fast_entry_scratch(xs, ws, len, wv_, fast_near(P, wv_, g, wv_ == 0 ? s : s2, first), fast_piv(P, wv_, g, wv_ == 0 ? s : s2, first), P.RM, lane_);
+            }
+        }
     }
 }
 
@@ -1129,11 +1142,11 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
             // the leading rows of the two decay tables (those above the cut for at least one pivot, at most vals) into LDS
             if (tid < 2) s_mc[tid] = 0;
             __syncthreads();
-            for (int x = tid; x < r0; x += blockDim.x) atomicMax(&s_mc[0], (int)P.fPiv[0][(size_t)g * TTX_FS * P.RM + FP_N * P.RM + x]);
-            for (int x = tid; x < r2; x += blockDim.x) atomicMax(&s_mc[1], (int)P.fPiv[1][(size_t)g * TTX_FS * P.RM + FP_N * P.RM + x]);
+            for (int x = tid; x < r0; x += blockDim.x) atomicMax(&s_mc[0], (int)fast_piv(P, 0, g, p - 1, first)[FP_N * P.RM + x]);
+            for (int x = tid; x < r2; x += blockDim.x) atomicMax(&s_mc[1], (int)fast_piv(P, 1, g, p + 1, first)[FP_N * P.RM + x]);
             __syncthreads();
             fcap = min(vals, max(s_mc[0], s_mc[1]));
-            const double *nL = P.fNear[0] + (size_t)g * P.FD * P.RM, *nR = P.fNear[1] + (size_t)g * P.FD * P.RM;
+            const double *nL = fast_near(P, 0, g, p - 1, first), *nR = fast_near(P, 1, g, p + 1, first);
             for (int x = tid; x < fcap * P.RM; x += blockDim.x) { const int c = x % P.RM; sNL[x] = (c < r0) ? nL[x] : 0.0; sNR[x] = (c < r2) ? nR[x] : 0.0; }
         }
     } else if (usem) {
@@ -1216,7 +1229,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         double f;
         if (phase == 2) f = P.lotf[(size_t)g * P.lot_max + il];
         else if (fastp) f = (FUN == FUN_MVN) ? mvn_fast_value(P, g, p, i - 1, j - 1, k - 1, q - 1, mvn_fast_cross(P, g, p, i - 1, q - 1))
-                                             : de_fast_elem4(P, g, i - 1, j - 1, k - 1, q - 1, sNL, sNR, fcap);
+                                             : de_fast_elem4(P, g, p, first, i - 1, j - 1, k - 1, q - 1, sNL, sNR, fcap);
         else if (usem) f = f_mvn_rows<2>(m, P.auxT, P.mvn_norm, DLv + (size_t)(i - 1) * VS, p - 1, par[j - 1] - P.aux[p - 1], par[k - 1] - P.aux[p],
                                     DRv + (size_t)(q - 1) * VS);
         else if (FUN == FUN_ISING && P.ising_id != 1 && P.deTL) {
@@ -1340,7 +1353,8 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     const int fside = iscol ? 0 : 1;                                         // the varying side
     const int vfix = iscol ? cur.qq - 1 : cur.ii - 1, xfix = iscol ? cur.kk - 1 : cur.jj - 1;   // fixed pivot (other side), fixed mode index next to the free dim
     if (fastp && FUN == FUN_ISING) {
-        const double *nearO = P.fNear[1 - fside] + (size_t)g * P.FD * P.RM + vfix, *pO = P.fPiv[1 - fside] + (size_t)g * TTX_FS * P.RM + vfix;
+        const int bO = fside == 0 ? p + 1 : p - 1;             // the bond whose pivot set holds the fixed pivot
+        const double *nearO = fast_near(P, 1 - fside, g, bO, first) + vfix, *pO = fast_piv(P, 1 - fside, g, bO, first) + vfix;
         const int cntO = (int)pO[FP_N * P.RM];
         const double xf = P.par[xfix];
         if (tid == 0) far[0] = 1.0;
@@ -1418,8 +1432,9 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
         if (iscol) { u = t % r0; v = t / r0; } else { u = t % n2; v = t / n2; }
         if (fastp && FUN == FUN_ISING) {
             const int pv = iscol ? u : v, nd = iscol ? v : u;                // varying pivot, free mode index (0-based)
-            const double *nearV = P.fNear[fside] + (size_t)g * P.FD * P.RM + pv, *pV = P.fPiv[fside] + (size_t)g * TTX_FS * P.RM + pv;
-            const double *pO = P.fPiv[1 - fside] + (size_t)g * TTX_FS * P.RM + vfix;
+            const int bV = fside == 0 ? p - 1 : p + 1;
+            const double *nearV = fast_near(P, fside, g, bV, first) + pv, *pV = fast_piv(P, fside, g, bV, first) + pv;
+            const double *pO = fast_piv(P, 1 - fside, g, fside == 0 ? p + 1 : p - 1, first) + vfix;
             const double xn = par[nd], xf = par[xfix];
             double N = 1.0, D = 1.0;
             if (s_nfar <= TTX_FNR) {
@@ -1615,6 +1630,15 @@ __global__ __launch_bounds__(TTX_BLK) void k_accept(DevProb P, int H, int nA)
         const short *Lo = L_ptr(P, g, p - 1, first), *Ro = R_ptr(P, g, p + 1, first);
         for (int x = tid; x < p; x += TTX_BLK) Ln[(size_t)x * P.RM + r1] = (x < p - 1) ? Lo[(size_t)x * P.RM + ii] : (short)(jj + 1);
         for (int x = tid; x < m - p; x += TTX_BLK) Rn[(size_t)x * P.RM + r1] = (x == 0) ? (short)(kk + 1) : Ro[(size_t)(x - 1) * P.RM + qq];
+        if (P.arith && P.fpersist && tid < 128) {
+            // TTX_ARITH=fast, Ising D/E: the table entries of the new pivot as a LEFT multi-index of bond p (parent: left pivot ii of bond
+            // p-1, extended by node jj) and as a RIGHT multi-index of bond p (parent: right pivot qq of bond p+1, extended by node kk)
+            const int sd = tid >> 6, lane_ = tid & 63;
+            const double *pn = fast_near(P, sd, g, sd == 0 ? p - 1 : p + 1, first) + (sd == 0 ? ii : qq);
+            const double *pp_ = fast_piv(P, sd, g, sd == 0 ? p - 1 : p + 1, first) + (sd == 0 ? ii : qq);
+            const int nd = sd == 0 ? jj : kk;
+            fast_entry_child(pn, pp_, P.par[nd], P.par[P.n[1] + nd], fast_near(P, sd, g, p, first) + r1, fast_piv(P, sd, g, p, first) + r1, P.RM, lane_);
+        }
         if (tid == 0) {
             gI[(r1 + 1) * (r1 + 1) - 1] = cur.pivot;
             int *vp = vip_ptr(P, g, p, first) + 4 * r1;
@@ -1946,6 +1970,13 @@ __device__ __forceinline__ void exch_apply_group(const DevProb &P, int g)
         double *gI = inv_ptr(P, g, bl, first);
         for (int x = tid; x < rnew * rnew; x += blockDim.x) gI[x] = dd[(size_t)P.RM * P.NM + x];
         if (tid == 0) { upd[bl] = u; r[bl] = rnew; }
+        if (u && P.arith && P.fpersist && tid < 64) {        // fast tables: the neighbour's new pivot as a left multi-index of bond bl, from scratch
+            extern __shared__ __align__(16) double dyn_x[];
+            double *xs = dyn_x, *ws = xs + m + 8;
+            for (int k = tid; k < bl; k += 64) { xs[k] = P.par[ix[k] - 1]; ws[k] = P.par[P.n[1] + ix[k] - 1]; }
+            __builtin_amdgcn_wave_barrier();
+            fast_entry_scratch(xs, ws, bl, 0, fast_near(P, 0, g, bl, first) + (rnew - 1), fast_piv(P, 0, g, bl, first) + (rnew - 1), P.RM, tid);
+        }
     }
     if (P.inR[g]) {
         const int br = last + 1;
@@ -1953,6 +1984,14 @@ __device__ __forceinline__ void exch_apply_group(const DevProb &P, int g)
         const int u = hh[0], rnew = hh[1];
         if (u) { short *Rt = R_ptr(P, g, br, first); for (int x = tid; x < m - br; x += blockDim.x) Rt[(size_t)x * P.RM + (rnew - 1)] = (short)ix[x]; }
         if (tid == 0) { upd[br] = u; r[br] = rnew; }
+        if (u && P.arith && P.fpersist && tid >= 64 && tid < 128) {   // ... and as a right multi-index of bond br
+            extern __shared__ __align__(16) double dyn_x[];
+            double *xs = dyn_x + 2 * (m + 8), *ws = xs + m + 8;
+            const int lane_ = tid - 64;
+            for (int k = lane_; k < m - br; k += 64) { xs[k] = P.par[ix[k] - 1]; ws[k] = P.par[P.n[1] + ix[k] - 1]; }
+            __builtin_amdgcn_wave_barrier();
+            fast_entry_scratch(xs, ws, m - br, 1, fast_near(P, 1, g, br, first) + (rnew - 1), fast_piv(P, 1, g, br, first) + (rnew - 1), P.RM, lane_);
+        }
     }
 }
 
