@@ -1,0 +1,12 @@
+# final measurements of round 3 (run through gpurun; ~10 minutes)
+R=$GRAFT_REPO_ROOT
+cd $R
+for w in "c64 exact" "c64 fast" "d256 fast" "mvn128 fast" "d256 exact" "mvn128 exact"; do set -- $w; bash profiles/measure_r03.sh $1 $2 > gpurun_out/m_$1_$2.log 2>&1; echo "$1 $2 profiled"; done
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/r03_bench_c64_exact_g8.json 2> gpurun_out/b1.err; echo c64 exact done
+python3 bench.py --arith fast --steps 20 --warmup 5 > gpurun_out/r03_bench_c64_fast_g8.json 2> gpurun_out/b2.err; echo c64 fast done
+python3 bench.py --workload d256 --arith fast --steps 3 --warmup 1 > gpurun_out/r03_bench_d256_fast_g8.json 2> gpurun_out/b3.err; echo d256 fast done
+python3 bench.py --workload d256 --arith exact --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/r03_bench_d256_exact_g8.json 2> gpurun_out/b4.err; echo d256 exact done
+python3 bench.py --workload mvn128 --arith fast --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r03_bench_mvn128_fast_g4.json 2> gpurun_out/b5.err; echo mvn fast done
+python3 bench.py --workload mvn128 --arith exact --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03_bench_mvn128_exact_g4.json 2> gpurun_out/b6.err; echo mvn exact done
+python3 bench.py --workload svd_d64 --steps 5 --warmup 2 > gpurun_out/r03_bench_svd_d64.json 2> gpurun_out/b7.err; python3 bench.py --workload ort_d64 --steps 5 --warmup 2 > gpurun_out/r03_bench_ort_d64.json 2> gpurun_out/b8.err; echo n1 done
+TTX_LIB=$R/ttcross_amd/lib/libttx_stamps.so python3 profiles/probes/stamps_run.py c64 > gpurun_out/r03_stamps_c64.txt 2>&1; echo stamps done

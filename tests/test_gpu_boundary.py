@@ -128,6 +128,32 @@ def test_host_callback_accchk(userfun):
     assert np.array_equal(got["pivot"], oo["accchk"]["pivot"])
 
 
+def test_host_callbacks_of_two_engines_in_two_threads(userfun):
+    """Two engines driven from two host threads share the process-wide worker pool of the host integrand: their batches take
+    turns on it (ctypes releases the GIL inside ttx_run, so the two runs really overlap).  Both must equal the oracle."""
+    import threading
+    _, addr = userfun
+    cases = [(5, 17, 10, 2), (6, 13, 8, 1)]
+    out = [None, None]
+
+    def job(i):
+        d, n, r, piv = cases[i]
+        s = _user_setup(d, n)
+        tt = E.TTCross(s["n"], E.TTX_FUN_HOST, [], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"])
+        tt.set_integrand_host(addr, s["par"]).run()
+        out[i] = (tt.neval, tt.quad(s["quad"]), [tt.core(k) for k in range(1, d + 1)])
+        tt.close()
+
+    th = [threading.Thread(target=job, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i, (d, n, r, piv) in enumerate(cases):
+        s = _user_setup(d, n)
+        oo = O.dmrgg(s["n"], 4, s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], user=addr)
+        assert out[i] is not None and out[i][0] == oo["neval"] and out[i][1] == oo["value"]
+        assert all(np.array_equal(a, b) for a, b in zip(out[i][2], oo["cores"]))
+
+
 def test_host_callback_needs_the_function():
     s = _user_setup(4, 9)
     tt = E.TTCross(s["n"], E.TTX_FUN_HOST, [], 6, pivoting=1, accuracy=s["acc"])

@@ -176,11 +176,13 @@ class HostPool {
   public:
     static HostPool &get() { static HostPool p; return p; }
     int threads() const { return (int)workers.size() + 1; }
-    // fn(i) for i in [0, n): the calling thread takes part; returns when all are done
+    // fn(i) for i in [0, n): the calling thread takes part; returns when all are done.  The pool is one per process:
+    // engines driven from different host threads take turns on it, one batch at a time (`turn`).
     void run(size_t n, const std::function<void(size_t)> &fn)
     {
         if (n == 0) return;
         if (workers.empty() || n < 32) { for (size_t i = 0; i < n; i++) fn(i); return; }
+        std::lock_guard<std::mutex> one_batch(turn);
         {
             std::lock_guard<std::mutex> lk(mu);
             job = &fn; total = n; next = 0; pending = workers.size(); gen++;
@@ -233,7 +235,7 @@ class HostPool {
         }
     }
     std::vector<std::thread> workers;
-    std::mutex mu;
+    std::mutex mu, turn;
     std::condition_variable cv, done;
     const std::function<void(size_t)> *job = nullptr;
     size_t total = 0, next = 0, pending = 0;
