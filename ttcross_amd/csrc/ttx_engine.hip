@@ -15,6 +15,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <random>
 #include <string>
@@ -2138,21 +2139,65 @@ static int gemm(ttx_engine *h, int M, int N, int K, const double *A, int lda, co
     hipLaunchKernelGGL(k_gemm_mfma, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, h->stream, M, N, K, A, lda, B, ldb, C, ldc);
     return TTX_OK;
 }
-// Tall-skinny QR of A (m x n, m >> n) over several workgroups (ttx_ttops.h): levels of LDS-resident panel factorisations, then
+// ---- QR of an unfolding ------------------------------------------------------------------------------------------------
+// k_qr_own<MR, NC> (matrix in registers, one barrier per reflector, ttx_ttops.h): NC = columns per wave, MR = rows per lane
+struct QrOwnShape { int nt, mr, nc, rows_cap; };
+static QrOwnShape qr_own_shape(int n)
+{
+    QrOwnShape s{0, 0, 0, 0};
+    if (n < 1 || n > 128 || (getenv("TTX_QR_OWN") && atoi(getenv("TTX_QR_OWN")) == 0)) return s;
+    s.nt = tt_threads("TTX_QR_THREADS", 1024);
+    const int nw = s.nt / 64;
+    int nc = 1; while (nc * nw < n) nc *= 2;
+    if (nc > 8) return QrOwnShape{0, 0, 0, 0};
+    s.nc = nc;
+    s.mr = nc <= 2 ? 8 : 4;                                                  // rows per lane the instantiations hold without spilling
+    const size_t budget = 150 * 1024 / sizeof(double);
+    const long lds_rows = (long)((budget - (size_t)n - 4) / (size_t)n);
+    s.rows_cap = (int)std::min<long>(64L * s.mr, lds_rows);
+    return s;
+}
+// one launch over P panels of rbs rows (P = 1, rbs = rows: the whole matrix); false: shape not covered
+static bool qr_own_launch(ttx_engine *h, const QrOwnShape &s, int rows, int n, int rbs, int P, const double *M, int ldm, double *Q, int ldq,
+                          double *R, int ldr, int rstep, double *tau, int *rc_out)
+{
+    int mr = 1; while (mr * 64 < rbs) mr *= 2;
+    if (mr < 2) mr = 2;
+    if (mr > s.mr) return false;
+    const size_t lds = sizeof(double) * qr_own_lds_doubles(rbs, n);
+    const void *fn = nullptr;
+#define QRO(MRv, NCv) if (mr == MRv && s.nc == NCv) fn = reinterpret_cast<const void *>(k_qr_own<MRv, NCv>);
+    QRO(2, 1) QRO(4, 1) QRO(8, 1) QRO(2, 2) QRO(4, 2) QRO(8, 2) QRO(2, 4) QRO(4, 4) QRO(2, 8) QRO(4, 8)
+#undef QRO
+    if (!fn) return false;
+    static std::map<const void *, size_t> lds_set;
+    if ((*rc_out = ensure_lds(fn, lds, lds_set[fn]))) return true;
+    void *args[] = {&rows, &n, &rbs, &M, &ldm, &Q, &ldq, &R, &ldr, &rstep, &tau};
+    hipError_t e = hipLaunchKernel(fn, dim3(P), dim3(s.nt), args, lds, h->stream);
+    if (e != hipSuccess) *rc_out = fail(TTX_EHIP, "k_qr_own: %s", hipGetErrorString(e));
+    return true;
+}
+// Tall-skinny QR of A (m x n, m >> n) over several workgroups (ttx_ttops.h): levels of panel factorisations side by side, then
 // the explicit Q from the top level down.  Scratch: Wb (Q panels of level 0), Wc (stacked triangles of the levels / their
 // accumulated Q), Wd (Q panels of the levels >= 1) -- all free while a qr() is running.  false: shape not eligible.
 static bool qr_tsqr(ttx_engine *h, int m, int n, double *A, double *R, double *tau, int *rc_out)
 {
     *rc_out = TTX_OK;
     if (A != h->Wa || n > 96 || m < 4 * n || (getenv("TTX_TSQR") && atoi(getenv("TTX_TSQR")) == 0)) return false;
+    const QrOwnShape own = qr_own_shape(n);
+    const bool use_own = own.nt && own.rows_cap >= 2 * n;
     const size_t budget = 150 * 1024 / sizeof(double);
-    const int RB = (int)((budget - 2 * n - 2) / (size_t)(n + 1));            // rows of a panel that fits with its reflector
+    // rows of a panel: the register kernel's time per reflector grows with the rows per lane, so its panels are short (4 n rows,
+    // at least 128); the LDS kernel takes what fits with its reflector
+    int RB = use_own ? std::min(own.rows_cap, std::max(128, 4 * n)) : (int)((budget - 2 * n - 2) / (size_t)(n + 1));
+    if (const char *e = getenv("TTX_QR_PANEL")) if (use_own && atoi(e) >= 2 * n) RB = std::min(own.rows_cap, atoi(e));
     if (RB < 2 * n) return false;
     struct Lvl { int rows, P, rbs; double *M, *Q; };
     std::vector<Lvl> lv;
     double *Sbuf = h->Wc, *Tbuf = h->Wd;
     int rows = m; double *M = A;
-    while ((size_t)rows * n + rows + 2 * n + 4 > budget) {                      // until one workgroup's LDS takes the rest
+    auto top_fits = [&](int rws) { return use_own ? rws <= own.rows_cap : (size_t)rws * n + rws + 2 * n + 4 <= budget; };
+    while (!top_fits(rows)) {                                                   // until one workgroup takes the rest
         const int P = (rows + RB - 1) / RB, rbs = (rows + P - 1) / P;
         if (rows - (P - 1) * rbs < n) return false;                             // a last panel shorter than n: keep the one-workgroup path
         Lvl L{rows, P, rbs, M, lv.empty() ? h->Wb : Tbuf};
@@ -2165,15 +2210,21 @@ static bool qr_tsqr(ttx_engine *h, int m, int n, double *A, double *R, double *t
     for (size_t l = 0; l < lv.size(); l++) {
         const Lvl &L = lv[l];
         double *Rst = (l + 1 < lv.size()) ? lv[l + 1].M : M;                    // the next level's matrix (P n x n)
+        if (use_own && qr_own_launch(h, own, L.rows, n, L.rbs, L.P, L.M, L.rows, L.Q, L.rows, Rst, L.P * n, n, nullptr, rc_out)) {
+            if (*rc_out) return true;
+            continue;
+        }
         const size_t lds = sizeof(double) * qr_panel_lds_doubles(L.rbs, n);
         if ((*rc_out = ensure_lds(reinterpret_cast<const void *>(k_qr_panel), lds, a_qp))) return true;
         hipLaunchKernelGGL(k_qr_panel, dim3(L.P), dim3(tt_threads("TTX_QR_THREADS", 1024)), lds, h->stream, L.rows, n, L.rbs, L.M, L.Q, Rst, L.P * n);
     }
-    {   // top: one workgroup, in place: M -> Q_top (rows x n), R (n x n)
+    // top: one workgroup, in place: M -> Q_top (rows x n), R (n x n)
+    if (!(use_own && qr_own_launch(h, own, rows, n, rows, 1, M, rows, M, rows, R, std::min(rows, n), 0, tau, rc_out))) {
         const size_t lds_all = sizeof(double) * ((size_t)rows + 2 * n + 4 + (size_t)rows * n);
         if ((*rc_out = ensure_lds(reinterpret_cast<const void *>(k_qr<true>), lds_all, a_q1))) return true;
         hipLaunchKernelGGL(k_qr<true>, dim3(1), dim3(tt_threads("TTX_QRTOP_THREADS", 1024)), lds_all, h->stream, rows, n, M, R, tau);
     }
+    if (*rc_out) return true;
     // explicit Q, top down: Qacc(level l) = blockdiag(Q_p) * Qacc(level l+1); level l's own matrix buffer takes the result
     const double *Qup = M; int ldup = rows;
     for (int l = (int)lv.size() - 1; l >= 0; l--) {
@@ -2188,6 +2239,11 @@ static bool qr_tsqr(ttx_engine *h, int m, int n, double *A, double *R, double *t
 static int qr(ttx_engine *h, int m, int n, double *A, double *R, double *tau)
 {
     { int rc = TTX_OK; if (qr_tsqr(h, m, n, A, R, tau, &rc)) return rc; }
+    {   // small unfoldings: one workgroup, matrix in registers
+        const QrOwnShape own = qr_own_shape(n);
+        int rc = TTX_OK;
+        if (own.nt && m <= own.rows_cap && qr_own_launch(h, own, m, n, m, 1, A, m, A, m, R, std::min(m, n), 0, tau, &rc)) return rc;
+    }
     const size_t lds = sizeof(double) * ((size_t)m + n + 4);
     if (lds > 150 * 1024) return fail(TTX_EINVAL, "dtt_ort: unfolding with %d rows does not fit the LDS-staged reflector", m);
     // small unfoldings are factored entirely inside LDS; larger ones stream the panel from L2 with threads mapped to rows

@@ -193,6 +193,129 @@ __device__ __forceinline__ void qr_lds3(double *A, int m, int n, double *vsh, do
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Householder QR with the matrix in REGISTERS and one workgroup barrier per reflector (round 3, second version).
+// Wave w owns the columns c = w, w + nw, w + 2 nw, ...; lane l holds the rows l, l + 64, ... of them (a[NC][MR]).  Only the
+// reflectors live in LDS (V, m x mn, and their taus).  Step i: the owner of column i+1 applies reflector i to that column FIRST,
+// forms reflector i+1 from it (norm by a DPP wave sum, dlarfg scalars in every lane) and publishes it, then updates its other
+// columns; every other wave applies reflector i to its columns; one barrier; next step.  The critical path per reflector is one
+// LDS read of v, two wave sums and the dlarfg scalars -- no phase is separated from the next by more than that one barrier
+// (qr_lds3 above needs three, and walks LDS for every element).  dorg2r needs no barrier at all: column c of Q is
+// H_0 ... H_c e_c, formed by the owning wave in registers from the read-only reflectors and written straight to global memory.
+// Panel p = blockIdx.x: rows [p rbs, p rbs + m) of M (leading dimension ldm) -> Q_p (m x mn) into the same rows of Qout (ldq; in
+// place allowed), R_p (mn x n, zeros below the diagonal) at Rst + p rstep (ldr), taus at tau_out + p n (may be null).
+// The host guarantees m <= 64 MR, n <= nw NC, (m mn + n + 2) doubles of dynamic LDS.
+// ------------------------------------------------------------------------------------------------------------------
+template <int MR, int NC>
+__global__ __launch_bounds__(1024) void k_qr_own(int rows, int n, int rbs, const double *M, int ldm, double *Qout, int ldq, double *Rst, int ldr, int rstep,
+                                                 double *tau_out)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int p = blockIdx.x, r0 = p * rbs, m = min(rbs, rows - r0), mn = m < n ? m : n;
+    double *tauv = sm;
+    double *V = sm + ((n + 2) & ~1);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    double a[NC][MR];
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const int c = wv + nw * k;
+#pragma unroll
+        for (int j = 0; j < MR; j++) { const int r = lane + 64 * j; a[k][j] = (c < n && r < m) ? M[r0 + r + (size_t)ldm * c] : 0.0; }
+    }
+    // reflector i from the (fully updated) column i held in slot ks of this wave: V(:, i), tauv[i]; the column keeps beta
+    auto make_reflector = [&](int i, int ks) {
+        double col[MR];
+#pragma unroll
+        for (int j = 0; j < MR; j++) { col[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < NC; k++) if (k == ks) col[j] = a[k][j]; }
+        double cand = 0.0, q = 0.0;
+#pragma unroll
+        for (int j = 0; j < MR; j++) { const int r = lane + 64 * j; if (j == (i >> 6)) cand = col[j]; if (r > i) q += col[j] * col[j]; }
+        const double alpha = __shfl(cand, i & 63, 64);
+        const double xn2 = jac_group_sum(q, 64, lane);
+        double tau = 0.0, beta = alpha, sc = 0.0;
+        if (xn2 != 0.0) {
+            beta = -copysign(hypot(alpha, sqrt(xn2)), alpha);
+            tau = (beta - alpha) / beta; sc = 1.0 / (alpha - beta);
+        }
+#pragma unroll
+        for (int j = 0; j < MR; j++) {
+            const int r = lane + 64 * j;
+            if (r >= i && r < m) V[r + (size_t)m * i] = (r == i) ? 1.0 : col[j] * sc;
+            const double nv = (r == i) ? beta : (r > i) ? 0.0 : col[j];
+#pragma unroll
+            for (int k = 0; k < NC; k++) if (k == ks) a[k][j] = nv;
+        }
+        if (lane == 0) tauv[i] = tau;
+    };
+    auto apply = [&](int k, const double *v, double tau) {          // a[k] -= tau (v' a[k]) v
+        double q = 0.0;
+#pragma unroll
+        for (int j = 0; j < MR; j++) q += v[j] * a[k][j];
+        q = jac_group_sum(q, 64, lane) * tau;
+#pragma unroll
+        for (int j = 0; j < MR; j++) a[k][j] -= v[j] * q;
+    };
+    if (wv == 0 && mn > 0) make_reflector(0, 0);
+    __syncthreads();
+    for (int i = 0; i < mn; i++) {
+        double v[MR];
+#pragma unroll
+        for (int j = 0; j < MR; j++) { const int r = lane + 64 * j; v[j] = (r >= i && r < m) ? V[r + (size_t)m * i] : 0.0; }
+        const double tau = tauv[i];
+        const int nx = i + 1, kx = nx / nw;                              // the next column and its slot in its owner
+        const bool mine = (nx < n) && (nx % nw == wv);
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) if (k == kx) apply(k, v, tau);
+            if (nx < mn) make_reflector(nx, kx);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const int c = wv + nw * k;
+            if (c > i && c < n && !(mine && k == kx)) apply(k, v, tau);
+        }
+        __syncthreads();
+    }
+    // R: rows r <= c of column c are final since step r
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const int c = wv + nw * k;
+        if (c < n) {
+#pragma unroll
+            for (int j = 0; j < MR; j++) { const int r = lane + 64 * j; if (r < mn) Rst[(size_t)p * rstep + r + (size_t)ldr * c] = (r <= c) ? a[k][j] : 0.0; }
+        }
+    }
+    if (tau_out) for (int x = tid; x < mn; x += blockDim.x) tau_out[(size_t)p * n + x] = tauv[x];
+    // Q = H_0 ... H_{mn-1} (first mn columns), column by column in the owner's registers
+    int cmax = -1;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const int c = wv + nw * k;
+        if (c < mn) cmax = c;
+#pragma unroll
+        for (int j = 0; j < MR; j++) a[k][j] = (lane + 64 * j == c) ? 1.0 : 0.0;
+    }
+    for (int i = cmax; i >= 0; i--) {
+        double v[MR];
+#pragma unroll
+        for (int j = 0; j < MR; j++) { const int r = lane + 64 * j; v[j] = (r >= i && r < m) ? V[r + (size_t)m * i] : 0.0; }
+        const double tau = tauv[i];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { const int c = wv + nw * k; if (c < mn && c >= i) apply(k, v, tau); }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const int c = wv + nw * k;
+        if (c < mn) {
+#pragma unroll
+            for (int j = 0; j < MR; j++) { const int r = lane + 64 * j; if (r < m) Qout[r0 + r + (size_t)ldq * c] = a[k][j]; }
+        }
+    }
+}
+__host__ __device__ inline size_t qr_own_lds_doubles(int m, int n) { return (size_t)((n + 2) & ~1) + (size_t)m * (m < n ? m : n); }
+
 // INLDS: the whole unfolding is staged in LDS (m n doubles <= the budget the host checked), factored there and written back
 template <bool INLDS>
 __global__ __launch_bounds__(1024) void k_qr(int m, int n, double *Ag, double *Rout, double *tau_out)
