@@ -2188,8 +2188,8 @@ static bool qr_tsqr(ttx_engine *h, int m, int n, double *A, double *R, double *t
     const bool use_own = own.nt && own.rows_cap >= 2 * n;
     const size_t budget = 150 * 1024 / sizeof(double);
     // rows of a panel: the register kernel's time per reflector grows with the rows per lane, so its panels are short (4 n rows,
-    // at least 128); the LDS kernel takes what fits with its reflector
-    int RB = use_own ? std::min(own.rows_cap, std::max(128, 4 * n)) : (int)((budget - 2 * n - 2) / (size_t)(n + 1));
+    // at least 256 -- measured optimum for n = 32); the LDS kernel takes what fits with its reflector
+    int RB = use_own ? std::min(own.rows_cap, std::max(256, 4 * n)) : (int)((budget - 2 * n - 2) / (size_t)(n + 1));
     if (const char *e = getenv("TTX_QR_PANEL")) if (use_own && atoi(e) >= 2 * n) RB = std::min(own.rows_cap, atoi(e));
     if (RB < 2 * n) return false;
     struct Lvl { int rows, P, rbs; double *M, *Q; };

@@ -232,11 +232,18 @@ __global__ __launch_bounds__(1024) void k_qr_own(int rows, int n, int rbs, const
         double cand = 0.0, q = 0.0;
 #pragma unroll
         for (int j = 0; j < MR; j++) { const int r = lane + 64 * j; if (j == (i >> 6)) cand = col[j]; if (r > i) q += col[j] * col[j]; }
-        const double alpha = __shfl(cand, i & 63, 64);
+        // alpha from its lane (the index is wave-uniform: v_readlane, no LDS round trip), the norm by one DPP wave sum; dlapy2 as
+        // a plain sqrt(alpha^2 + xn2) while that cannot over- or underflow (hypot costs more than the rest of the scalar chain)
+        const int al_lane = i & 63;
+        const long long cb = __double_as_longlong(cand);
+        const double alpha = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(cb >> 32), al_lane) << 32) |
+                                                  (unsigned int)__builtin_amdgcn_readlane((int)cb, al_lane));
         const double xn2 = jac_group_sum(q, 64, lane);
         double tau = 0.0, beta = alpha, sc = 0.0;
         if (xn2 != 0.0) {
-            beta = -copysign(hypot(alpha, sqrt(xn2)), alpha);
+            const double s2 = alpha * alpha + xn2;
+            const double nrm = (s2 > 1e-280 && s2 < 1e280) ? sqrt(s2) : hypot(alpha, sqrt(xn2));
+            beta = -copysign(nrm, alpha);
             tau = (beta - alpha) / beta; sc = 1.0 / (alpha - beta);
         }
 #pragma unroll
@@ -552,6 +559,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *Xg, d
     // threads per pair: a power of two <= 64 so that a pair never straddles a wave
     int t2 = 1; while (t2 * 2 <= tpp) t2 *= 2; tpp = t2;
     const int pairs_per_pass = nt / tpp;
+    int ltpp = 0; while ((1 << ltpp) < tpp) ltpp++;
     // columns count as orthogonal at sqrt(p) eps (the criterion of LAPACK's one-sided Jacobi, dgesvj); a threshold BELOW eps (1e-16,
     // round 2) is met only by chance: 2 of the 62 cores of the D_64 train ran all 60 sweeps, the others 6-7
     const double jtol = 2.220446049250313e-16 * sqrt((double)p);
@@ -561,10 +569,13 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *Xg, d
         __syncthreads();
         for (int round = 0; round < qq - 1; round++) {
             for (int p0 = 0; p0 < npair; p0 += pairs_per_pass) {
-                const int pi = p0 + tid / tpp, sub = tid % tpp;
+                const int pi = p0 + (tid >> ltpp), sub = tid & (tpp - 1);
                 if (pi < npair) {
-                    int a = (pi == 0) ? qq - 1 : (round + pi) % (qq - 1);
-                    int b = (round - pi + (qq - 1)) % (qq - 1);
+                    // (round + pi) mod (qq - 1) and (round - pi) mod (qq - 1) by one conditional step each: an integer division is ~40
+                    // instructions at the head of every round's dependent chain
+                    int a = round + pi; if (a >= qq - 1) a -= qq - 1;
+                    if (pi == 0) a = qq - 1;
+                    int b = round - pi; if (b < 0) b += qq - 1;
                     if (a > b) { int t = a; a = b; b = t; }
                     if (b < q) {
                         double *xa = X + (size_t)p * a, *xb = X + (size_t)p * b;
@@ -572,11 +583,16 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *Xg, d
                         for (int i = sub; i < p; i += tpp) { double u = xa[i], w = xb[i]; al += u * u; be += w * w; ga += u * w; }
                         if (tpp >= 16) { al = jac_group_sum(al, tpp, tid & 63); be = jac_group_sum(be, tpp, tid & 63); ga = jac_group_sum(ga, tpp, tid & 63); }
                         else for (int o = tpp >> 1; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
-                        if (!(fabs(ga) <= jtol * sqrt(al * be) || ga == 0.0)) {
+                        // the test and the rotation with three long operations (sqrt, division, rsqrt) in the dependent chain of a round
+                        // instead of six: t = tan of the rotation angle, the smaller root of t^2 + 2 zeta t - 1 = 0 with
+                        // zeta = (be - al) / (2 ga), written without forming zeta
+                        const double ab = al * be;
+                        const bool orth = (ab < 1e300) ? (ga * ga <= jtol * jtol * ab) : (fabs(ga) <= jtol * sqrt(al) * sqrt(be));
+                        if (!(orth || ga == 0.0)) {
                             if (sub == 0) atomicAdd(&s_rot, 1);
-                            const double zeta = (be - al) / (2.0 * ga);
-                            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                            const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                            const double dd = be - al, g2 = 2.0 * ga;
+                            const double t = (dd >= 0.0 ? g2 : -g2) / (fabs(dd) + sqrt(dd * dd + g2 * g2));
+                            const double c = rsqrt(1.0 + t * t), sn = c * t;
                             for (int i = sub; i < p; i += tpp) { double u = xa[i], w = xb[i]; xa[i] = c * u - sn * w; xb[i] = sn * u + c * w; }
                             double *va = V + (size_t)q * a, *vb = V + (size_t)q * b;
                             for (int i = sub; i < q; i += tpp) { double u = va[i], w = vb[i]; va[i] = c * u - sn * w; vb[i] = sn * u + c * w; }
