@@ -408,12 +408,15 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
         P.arith = (want && !nofun && ((cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && unit) || cfg->fun_id == TTX_FUN_MVN)) ? 1 : 0;
         if (P.arith) {
             P.FD = d + 1;
-            P.fpersist = (cfg->fun_id == TTX_FUN_ISING) ? 1 : 0;       // Ising D/E: tables per bond, maintained incrementally (ttx_fast.h)
+            // tables per bond, kept for the whole run and extended incrementally (ttx_fast.h); TTX_FAST_PERSIST=0: mvn rebuilds the
+            // tables of a bond step's two pivot sets with k_fast_tables instead (the first version, kept as a cross-check)
+            P.fpersist = 1;
+            if (cfg->fun_id == TTX_FUN_MVN && getenv("TTX_FAST_PERSIST") && atoi(getenv("TTX_FAST_PERSIST")) == 0) P.fpersist = 0;
             const size_t slots = P.fpersist ? G * NC : G;
             for (int sd = 0; sd < 2; sd++) {
                 A_(dev_alloc(h, &P.fNear[sd], slots * (size_t)P.FD * RM));
                 A_(dev_alloc(h, &P.fPiv[sd], slots * (size_t)TTX_FS * RM));
-                if (cfg->fun_id == TTX_FUN_MVN) A_(dev_alloc(h, &P.fDv[sd], G * (size_t)P.FD * RM));
+                if (cfg->fun_id == TTX_FUN_MVN) A_(dev_alloc(h, &P.fDv[sd], slots * (size_t)P.FD * RM));
             }
             if (cfg->fun_id == TTX_FUN_MVN) {
                 std::vector<double> sy((size_t)d * d);

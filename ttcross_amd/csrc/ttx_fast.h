@@ -162,6 +162,8 @@ __device__ __forceinline__ double *fast_near(const DevProb &P, int side, int g, 
 { return P.fNear[side] + fast_slot(P, side, g, bond, first) * (size_t)P.FD * P.RM; }
 __device__ __forceinline__ double *fast_piv(const DevProb &P, int side, int g, int bond, int first)
 { return P.fPiv[side] + fast_slot(P, side, g, bond, first) * (size_t)TTX_FS * P.RM; }
+__device__ __forceinline__ double *fast_dv(const DevProb &P, int side, int g, int bond, int first)
+{ return P.fDv[side] + fast_slot(P, side, g, bond, first) * (size_t)P.FD * P.RM; }
 
 // Table entry of ONE pivot FROM SCRATCH by one wave (all 64 lanes call it).  xs / ws: node and weight values of the pivot's own
 // dims in natural order (len of them, LDS, visible to the wave); side 0: the bond lies behind the last dim, side 1: before the
@@ -292,27 +294,72 @@ __device__ __forceinline__ double de_fast_elem4(const DevProb &P, int g, int p, 
 }
 
 // mvn: cross term dL_i' S_LR dR_q = sum over the left dims a of dvL_i[a] * (S dR_q)[a]
-__device__ __forceinline__ double mvn_fast_cross(const DevProb &P, int g, int p, int i, int q)
+__device__ __forceinline__ double mvn_fast_cross(const DevProb &P, int g, int p, int first, int i, int q)
 {
     const int RM = P.RM;
-    const double *dv = P.fDv[0] + (size_t)g * P.FD * RM + i, *Y = P.fNear[1] + (size_t)g * P.FD * RM + q;
+    const double *dv = fast_dv(P, 0, g, p - 1, first) + i, *Y = fast_near(P, 1, g, p + 1, first) + q;
     double x = 0.0;
 #pragma unroll 8
     for (int a = 0; a < p - 1; a++) x = __builtin_fma(dv[(size_t)a * RM], Y[(size_t)a * RM], x);
     return x;
 }
 // mvn value of the element (left pivot i | j | k | right pivot q), 0-based, given the cross term X of (i, q)
-__device__ __forceinline__ double mvn_fast_value(const DevProb &P, int g, int p, int i, int j, int k, int q, double X)
+__device__ __forceinline__ double mvn_fast_value(const DevProb &P, int g, int p, int first, int i, int j, int k, int q, double X)
 {
     const int RM = P.RM, m = P.d;
-    const double *YL = P.fNear[0] + (size_t)g * P.FD * RM + i, *YR = P.fNear[1] + (size_t)g * P.FD * RM + q;
-    const double QL = P.fPiv[0][(size_t)g * TTX_FS * RM + FP_T * RM + i], QR = P.fPiv[1][(size_t)g * TTX_FS * RM + FP_T * RM + q];
+    const double *YL = fast_near(P, 0, g, p - 1, first) + i, *YR = fast_near(P, 1, g, p + 1, first) + q;
+    const double QL = fast_piv(P, 0, g, p - 1, first)[FP_T * RM + i], QR = fast_piv(P, 1, g, p + 1, first)[FP_T * RM + q];
     const double *S = P.auxS, *mu = P.aux;
     const double dj = P.par[j] - mu[p - 1], dk = P.par[k] - mu[p];
     const double yj = YL[(size_t)(p - 1) * RM] + YR[(size_t)(p - 1) * RM], yk = YL[(size_t)p * RM] + YR[(size_t)p * RM];
     const double sjj = S[(size_t)(p - 1) * (m + 1)], skk = S[(size_t)p * (m + 1)], sjk = S[(size_t)(p - 1) + (size_t)m * p];
     const double Q = (QL + QR + 2 * X) + 2 * (dj * yj + dk * yk) + (sjj * dj * dj + skk * dk * dk + 2 * sjk * dj * dk);
     return ttx_exp(-0.5 * Q) / P.mvn_norm;
+}
+// mvn table entry of ONE pivot FROM SCRATCH by one wave: xs = dv = x - mu over the pivot's len dims (LDS, visible to the wave),
+// d0 = 0-based dimension of entry 0; columns (stride RM) dvo[len], Y[m] = S dv, piv[FP_T] = dv' S dv
+__device__ __forceinline__ void mvn_entry_scratch(const DevProb &P, const double *xs, int len, int d0, double *dvo, double *Y, double *piv, int lane)
+{
+    const int m = P.d, RM = P.RM;
+    const double *S = P.auxS;
+    for (int k = lane; k < len; k += 64) dvo[(size_t)k * RM] = xs[k];
+    double q = 0.0;
+    for (int row = lane; row < m; row += 64) {
+        double y = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < len; k++) y = __builtin_fma(S[(size_t)row + (size_t)m * (d0 + k)], xs[k], y);
+        Y[(size_t)row * RM] = y;
+        if (row >= d0 && row < d0 + len) q = __builtin_fma(xs[row - d0], y, q);
+    }
+    q = wave_sum(q);
+    if (lane == 0) piv[FP_T * RM] = q;
+}
+// ... and of a pivot that is its PARENT extended by one dimension (0-based dnew, deviation dval) next to the bond: side 0 appends
+// the dimension behind the parent's plen dims, side 1 puts it in front.  O(m) instead of O(m len).
+__device__ __forceinline__ void mvn_entry_child(const DevProb &P, int side, const double *pdv, const double *pY, const double *ppiv, int plen, int dnew,
+                                                double dval, double *cdv, double *cY, double *cpiv, int lane)
+{
+    const int m = P.d, RM = P.RM;
+    const double *S = P.auxS;
+    if (side == 0) { for (int k = lane; k < plen; k += 64) cdv[(size_t)k * RM] = pdv[(size_t)k * RM]; if (lane == 0) cdv[(size_t)plen * RM] = dval; }
+    else { for (int k = lane; k < plen; k += 64) cdv[(size_t)(k + 1) * RM] = pdv[(size_t)k * RM]; if (lane == 0) cdv[0] = dval; }
+    for (int row = lane; row < m; row += 64) cY[(size_t)row * RM] = __builtin_fma(S[(size_t)row + (size_t)m * dnew], dval, pY[(size_t)row * RM]);
+    if (lane == 0) cpiv[FP_T * RM] = ppiv[FP_T * RM] + 2.0 * dval * pY[(size_t)dnew * RM] + S[(size_t)dnew * (m + 1)] * dval * dval;
+}
+// mvn value of one arbitrary point by ONE wave (boundary corners): dv[m] in LDS; Q = dv' S dv with one row of S per lane
+__device__ __forceinline__ double mvn_fast_point_wave(const DevProb &P, const double *dv, int lane)
+{
+    const int m = P.d;
+    const double *S = P.auxS;
+    double q = 0.0;
+    for (int row = lane; row < m; row += 64) {
+        double y = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < m; k++) y = __builtin_fma(S[(size_t)row + (size_t)m * k], dv[k], y);
+        q = __builtin_fma(dv[row], y, q);
+    }
+    q = wave_sum(q);
+    return ttx_exp(-0.5 * q) / P.mvn_norm;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -338,20 +385,9 @@ __global__ __launch_bounds__(64) void k_fast_tables(DevProb P, int dir, int pp)
     if (FUN == FUN_MVN) {
         // dv = x - mu over the pivot's dims (0-based dim of entry k: k on the left, p+1+k on the right); Y = S dv; Q = dv' Y
         const int d0 = side == 0 ? 0 : p + 1;
-        const double *S = P.auxS, *mu = P.aux;
-        double *dvo = P.fDv[side] + (size_t)g * P.FD * RM;
-        for (int k = lane; k < len; k += 64) { const double dv = P.par[tab[(size_t)k * RM + c] - 1] - mu[d0 + k]; xs[k] = dv; dvo[(size_t)k * RM + c] = dv; }
+        for (int k = lane; k < len; k += 64) xs[k] = P.par[tab[(size_t)k * RM + c] - 1] - P.aux[d0 + k];
         __syncthreads();
-        double q = 0.0;
-        for (int row = lane; row < m; row += 64) {
-            double y = 0.0;
-#pragma unroll 4
-            for (int k = 0; k < len; k++) y = __builtin_fma(S[(size_t)row + (size_t)m * (d0 + k)], xs[k], y);
-            near[(size_t)row * RM + c] = y;
-            if (row >= d0 && row < d0 + len) q = __builtin_fma(xs[row - d0], y, q);
-        }
-        q = wave_sum(q);
-        if (lane == 0) piv[FP_T * RM + c] = q;
+        mvn_entry_scratch(P, xs, len, d0, fast_dv(P, side, g, side == 0 ? p - 1 : p + 1, first) + c, near + c, piv + c, lane);
         return;
     }
     const double *nodes = P.par - 1, *weights = P.par + P.n[1] - 1;

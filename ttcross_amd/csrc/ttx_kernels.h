@@ -839,10 +839,16 @@ __global__ __launch_bounds__(256) void k_init_factors(DevProb P)
             const int wv_ = tid >> 6, lane_ = tid & 63;
             if (wv_ < 2) {
                 double *xs = dyn_i + (size_t)wv_ * 2 * (m + 8), *ws = xs + m + 8;
-                const int len = wv_ == 0 ? s : m - s2, o0 = wv_ == 0 ? 1 : s2 + 1;
+                const int len = wv_ == 0 ? s : m - s2, o0 = wv_ == 0 ? 1 : s2 + 1, bnd = wv_ == 0 ? s : s2;
+                if (P.fun_id == FUN_MVN) {                     // mvn: dv = x - mu, Y = S dv, Q (entry k of the right side is dim s2 + k, 0-based)
+                    for (int k = lane_; k < len; k += 64) xs[k] = P.par[P.ind0[o0 + k] - 1] - P.aux[o0 - 1 + k];
+                    __builtin_amdgcn_wave_barrier();
+                    mvn_entry_scratch(P, xs, len, o0 - 1, fast_dv(P, wv_, g, bnd, first), fast_near(P, wv_, g, bnd, first), fast_piv(P, wv_, g, bnd, first), lane_);
+                } else {
                 for (int k = lane_; k < len; k += 64) { const int ix = P.ind0[o0 + k]; xs[k] = P.par[ix - 1]; ws[k] = P.par[P.n[1] + ix - 1]; }
                 __builtin_amdgcn_wave_barrier();
-                fast_entry_scratch(xs, ws, len, wv_, fast_near(P, wv_, g, wv_ == 0 ? s : s2, first), fast_piv(P, wv_, g, wv_ == 0 ? s : s2, first), P.RM, lane_);
+                fast_entry_scratch(xs, ws, len, wv_, fast_near(P, wv_, g, bnd, first), fast_piv(P, wv_, g, bnd, first), P.RM, lane_);
+                }
             }
         }
     }
@@ -1228,7 +1234,7 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
         lot[4 * il] = i; lot[4 * il + 1] = j; lot[4 * il + 2] = k; lot[4 * il + 3] = q;
         double f;
         if (phase == 2) f = P.lotf[(size_t)g * P.lot_max + il];
-        else if (fastp) f = (FUN == FUN_MVN) ? mvn_fast_value(P, g, p, i - 1, j - 1, k - 1, q - 1, mvn_fast_cross(P, g, p, i - 1, q - 1))
+        else if (fastp) f = (FUN == FUN_MVN) ? mvn_fast_value(P, g, p, first, i - 1, j - 1, k - 1, q - 1, mvn_fast_cross(P, g, p, first, i - 1, q - 1))
                                              : de_fast_elem4(P, g, p, first, i - 1, j - 1, k - 1, q - 1, sNL, sNR, fcap);
         else if (usem) f = f_mvn_rows<2>(m, P.auxT, P.mvn_norm, DLv + (size_t)(i - 1) * VS, p - 1, par[j - 1] - P.aux[p - 1], par[k - 1] - P.aux[p],
                                     DRv + (size_t)(q - 1) * VS);
@@ -1375,7 +1381,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
     }
     if (fastp && FUN == FUN_MVN) {
         const int nv = iscol ? r0 : r2;
-        for (int v_ = tid; v_ < nv; v_ += TTX_BLK) Xv[v_] = iscol ? mvn_fast_cross(P, g, p, v_, vfix) : mvn_fast_cross(P, g, p, vfix, v_);
+        for (int v_ = tid; v_ < nv; v_ += TTX_BLK) Xv[v_] = iscol ? mvn_fast_cross(P, g, p, first, v_, vfix) : mvn_fast_cross(P, g, p, first, vfix, v_);
     }
     __syncthreads();      // par is read below when staging values
     if (usev) {
@@ -1447,7 +1453,7 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             a = iscol ? de_fast_value(P.ising_id, P.RM, rho, pV, xn, par[n1m + nd], xf, par[n1m + xfix], pO)
                       : de_fast_value(P.ising_id, P.RM, rho, pO, xf, par[n1m + xfix], xn, par[n1m + nd], pV);
         } else if (fastp && FUN == FUN_MVN) {
-            a = iscol ? mvn_fast_value(P, g, p, u, v, xfix, vfix, Xv[u]) : mvn_fast_value(P, g, p, vfix, xfix, u, v, Xv[v]);
+            a = iscol ? mvn_fast_value(P, g, p, first, u, v, xfix, vfix, Xv[u]) : mvn_fast_value(P, g, p, first, vfix, xfix, u, v, Xv[v]);
         } else if (usev) {
             const double *fn = vbase + (size_t)vcols * 2 * VS, *fw = fn + VS;
             if (iscol) { const double *rn = vbase + (size_t)u * 2 * VS; a = f_ising_c3v(m, p - 1, rn, rn + VS, par[v], par[n1m + v], fn, fw); }
@@ -1637,6 +1643,11 @@ __global__ __launch_bounds__(TTX_BLK) void k_accept(DevProb P, int H, int nA)
             const double *pn = fast_near(P, sd, g, sd == 0 ? p - 1 : p + 1, first) + (sd == 0 ? ii : qq);
             const double *pp_ = fast_piv(P, sd, g, sd == 0 ? p - 1 : p + 1, first) + (sd == 0 ? ii : qq);
             const int nd = sd == 0 ? jj : kk;
+            if (P.fun_id == FUN_MVN) {       // mvn: the new dimension is p-1 (0-based) behind the left parent's p-1 dims, p in front of the right parent's m-p-1
+                const int dnew = sd == 0 ? p - 1 : p, plen = sd == 0 ? p - 1 : m - p - 1;
+                mvn_entry_child(P, sd, fast_dv(P, sd, g, sd == 0 ? p - 1 : p + 1, first) + (sd == 0 ? ii : qq), pn, pp_, plen, dnew, P.par[nd] - P.aux[dnew],
+                                fast_dv(P, sd, g, p, first) + r1, fast_near(P, sd, g, p, first) + r1, fast_piv(P, sd, g, p, first) + r1, lane_);
+            } else
             fast_entry_child(pn, pp_, P.par[nd], P.par[P.n[1] + nd], fast_near(P, sd, g, p, first) + r1, fast_piv(P, sd, g, p, first) + r1, P.RM, lane_);
         }
         if (tid == 0) {
@@ -1973,9 +1984,15 @@ __device__ __forceinline__ void exch_apply_group(const DevProb &P, int g)
         if (u && P.arith && P.fpersist && tid < 64) {        // fast tables: the neighbour's new pivot as a left multi-index of bond bl, from scratch
             extern __shared__ __align__(16) double dyn_x[];
             double *xs = dyn_x, *ws = xs + m + 8;
+            if (P.fun_id == FUN_MVN) {
+                for (int k = tid; k < bl; k += 64) xs[k] = P.par[ix[k] - 1] - P.aux[k];
+                __builtin_amdgcn_wave_barrier();
+                mvn_entry_scratch(P, xs, bl, 0, fast_dv(P, 0, g, bl, first) + (rnew - 1), fast_near(P, 0, g, bl, first) + (rnew - 1), fast_piv(P, 0, g, bl, first) + (rnew - 1), tid);
+            } else {
             for (int k = tid; k < bl; k += 64) { xs[k] = P.par[ix[k] - 1]; ws[k] = P.par[P.n[1] + ix[k] - 1]; }
             __builtin_amdgcn_wave_barrier();
             fast_entry_scratch(xs, ws, bl, 0, fast_near(P, 0, g, bl, first) + (rnew - 1), fast_piv(P, 0, g, bl, first) + (rnew - 1), P.RM, tid);
+            }
         }
     }
     if (P.inR[g]) {
@@ -1988,9 +2005,15 @@ __device__ __forceinline__ void exch_apply_group(const DevProb &P, int g)
             extern __shared__ __align__(16) double dyn_x[];
             double *xs = dyn_x + 2 * (m + 8), *ws = xs + m + 8;
             const int lane_ = tid - 64;
+            if (P.fun_id == FUN_MVN) {
+                for (int k = lane_; k < m - br; k += 64) xs[k] = P.par[ix[k] - 1] - P.aux[br + k];
+                __builtin_amdgcn_wave_barrier();
+                mvn_entry_scratch(P, xs, m - br, br, fast_dv(P, 1, g, br, first) + (rnew - 1), fast_near(P, 1, g, br, first) + (rnew - 1), fast_piv(P, 1, g, br, first) + (rnew - 1), lane_);
+            } else {
             for (int k = lane_; k < m - br; k += 64) { xs[k] = P.par[ix[k] - 1]; ws[k] = P.par[P.n[1] + ix[k] - 1]; }
             __builtin_amdgcn_wave_barrier();
             fast_entry_scratch(xs, ws, m - br, 1, fast_near(P, 1, g, br, first) + (rnew - 1), fast_piv(P, 1, g, br, first) + (rnew - 1), P.RM, lane_);
+            }
         }
     }
 }
@@ -2052,6 +2075,7 @@ __device__ __forceinline__ double mvn_corner_wave(const DevProb &P, const double
         dv[x] = par[ix] - P.aux[x];
     }
     __builtin_amdgcn_wave_barrier();
+    if (P.arith) return mvn_fast_point_wave(P, dv, lane);                     // TTX_ARITH=fast (ttx_fast.h)
     const double ex = mvn_quadform_wave(m, dv, -1, 0.0, P.auxT, tb, lane);
     return ttx_exp(-0.5 * ex) / P.mvn_norm;
 }
