@@ -83,8 +83,10 @@ def test_nan_integrand_neither_faults_nor_hangs(userfun, name, piv, nproc):
 
 NAN_CASES = [("c_node", 2, 1, {}), ("c_node", 2, 3, {}), ("c_node", 1, 2, {"TTX_SWEEP": "fused"}), ("c_node", 2, 2, {"TTX_SWEEP": "chain"}),
              ("c_node", 0, 1, {}), ("d_node", 2, 1, {}), ("d_node", 3, 2, {}), ("e_node", 1, 1, {"TTX_DE_TEAM_UNITS": "1000000"}),
-             ("d_weight", 2, 1, {}), ("d_weight", 2, 2, {"TTX_DE_TEAM_UNITS": "1000000"}), ("d_weight", 1, 1, {"TTX_DE_TEAM_UNITS": "0", "TTX_DE_TEAM6_UNITS": "1000000"}),
-             ("d_weight", 2, 1, {"TTX_DE_TEAM": "0"}), ("d_weight_fast", 2, 2, {}), ("d_weight_fast", 0, 1, {}), ("d_node", -1, 1, {}),
+             ("d_weight", 2, 2, {"TTX_DE_CUT": "0"}), ("d_weight", 3, 1, {"TTX_DE_LANE": "1"}),
+             ("d_weight", 2, 1, {}), ("d_weight", 2, 2, {"TTX_DE_CUT": "0", "TTX_DE_TEAM_UNITS": "1000000"}),
+             ("d_weight", 1, 1, {"TTX_DE_CUT": "0", "TTX_DE_TEAM_UNITS": "0", "TTX_DE_TEAM6_UNITS": "1000000"}),
+             ("d_weight", 2, 1, {"TTX_DE_CUT": "0", "TTX_DE_TEAM": "0"}), ("d_weight_fast", 2, 2, {}), ("d_weight_fast", 0, 1, {}), ("d_node", -1, 1, {}),
              ("mvn_inf", 2, 1, {}), ("mvn_inf", 1, 2, {}), ("mvn_inf_fast", 2, 2, {}), ("mvn_inf", -1, 1, {})]
 
 

@@ -407,6 +407,7 @@ def test_team_halfstep_fault_is_replayed_without_teams(monkeypatch):
     """k_halfstep_det reports a launch whose grid is smaller than the number of units (never expected: the host sizes the grid
     from its bound on the ranks) in ctl[3]; ttx_run must see the report after the run -- the finalisation used to clear it --,
     retire the teams for the engine and repeat the run.  TTX_DE_TEST_FAULT=2 gives the team launches of sweep 2 a grid of one."""
+    monkeypatch.setenv("TTX_DE_CUT", "0")                 # the wave teams belong to the full-table kernels of round 2
     monkeypatch.setenv("TTX_DE_TEST_FAULT", "2")
     monkeypatch.setenv("TTX_DE_TEAM_UNITS", "1000000")
     s = D.ising_setup("d", 20, 17)
@@ -619,17 +620,24 @@ def test_bad_bond_groups_are_refused(own):
         E.TTCross(s["n"], s["fun_id"], s["par"], 4, pivoting=2, accuracy=s["acc"], quad=s["quad"], nproc=len(own) - 1, mybonds=own)
 
 
-@pytest.mark.parametrize("env", [{"TTX_DE_FASTDIV": "0"}, {"TTX_LOTTERY_ROWS": "2"}, {"TTX_LOTTERY_WAVE": "0"}, {"TTX_DE_V5": "1"}, {"TTX_DE_V2": "0"},
-                                 {"TTX_DE_TEAM": "0"}, {"TTX_DE_TEAM_UNITS": "1000000"}, {"TTX_DE_TEAM_UNITS": "1000000", "TTX_DE_FASTDIV": "0"},
-                                 {"TTX_DE_TEAM_UNITS": "0", "TTX_DE_TEAM6_UNITS": "1000000"}],
-                         ids=["general_division", "lottery_rows_with_tables", "lottery_lane_per_candidate", "relay_halfstep", "lane_per_element",
-                              "wave_per_unit_halfstep", "team_halfstep_always", "team_halfstep_general_division", "six_wave_team_halfstep_always"])
+@pytest.mark.parametrize("env", [{}, {"TTX_DE_LANE": "1"}, {"TTX_DE_V2": "0"},
+                                 {"TTX_DE_CUT": "0"}, {"TTX_DE_CUT": "0", "TTX_DE_FASTDIV": "0"}, {"TTX_DE_CUT": "0", "TTX_LOTTERY_ROWS": "2"},
+                                 {"TTX_DE_CUT": "0", "TTX_LOTTERY_WAVE": "0"}, {"TTX_DE_CUT": "0", "TTX_DE_V5": "1"}, {"TTX_DE_CUT": "0", "TTX_DE_V2": "0"},
+                                 {"TTX_DE_CUT": "0", "TTX_DE_TEAM": "0"}, {"TTX_DE_CUT": "0", "TTX_DE_TEAM_UNITS": "1000000"},
+                                 {"TTX_DE_CUT": "0", "TTX_DE_TEAM_UNITS": "1000000", "TTX_DE_FASTDIV": "0"},
+                                 {"TTX_DE_CUT": "0", "TTX_DE_TEAM_UNITS": "0", "TTX_DE_TEAM6_UNITS": "1000000"}],
+                         ids=["compact_tables_default", "unit_cut_lane_per_element_no_tables", "compact_tables_generic_kernels",
+                              "full_tables_round2_default", "general_division", "lottery_rows_with_tables", "lottery_lane_per_candidate", "relay_halfstep",
+                              "lane_per_element", "wave_per_unit_halfstep", "team_halfstep_always", "team_halfstep_general_division",
+                              "six_wave_team_halfstep_always"])
 def test_ising_de_kernel_variants_bit_exact(env, monkeypatch):
-    """Every selectable variant of the D/E kernels gives the oracle's bits: the IEEE division instead of the short sequence for
-    nodes in [0,1], the row-wise lottery with the pivots' factor tables (default: without), the lottery and the boundary corners
-    with one lane per element, the four-wave relay half-step, the round-1 lane-per-element kernels, the half-step without the
-    16-wave teams (default: teams while the ranks are small) and with teams at every rank.  The second case has two bond groups
-    (boundary corners)."""
+    """Every selectable variant of the D/E kernels gives the oracle's bits.  Round 3 (default for nodes in [0,1]): the compact tables whose
+    rows end at the unit cut (k_de_ctables, k_halfstep_dec, k_lottery_eval_dec, the wave-per-corner evaluator), the same cut with one
+    lane per element and no tables, the compact tables through the generic lane-per-element kernels.  TTX_DE_CUT=0 -- the kernels
+    of round 2 on the full pair triangle: the IEEE division instead of the short sequence for nodes in [0,1], the row-wise lottery
+    with the pivots' factor tables (default: without), the lottery and the boundary corners with one lane per element, the
+    four-wave relay half-step, the round-1 lane-per-element kernels, the half-step without the 16-wave teams (default: teams while
+    the ranks are small) and with teams at every rank.  The second case has two bond groups (boundary corners)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for kind, m, n, r, piv, ng in [("d", 45, 9, 6, 2, 1), ("e", 38, 5, 5, 3, 2)]:

@@ -348,6 +348,180 @@ __global__ __launch_bounds__(64) void k_halfstep_de(DevProb P, int h, int dir, i
 }
 #undef UNI
 
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+// the bond-spanning tail of a row as de_run, ended where every lane's running product has reached the unit cut (the factors of a
+// lane that is already there are exactly 1)
+__device__ __forceinline__ void de_run_cut(double &a, double u, double x2, const double *xr, int B)
+{
+    u = u * x2; a = a * de_t2<true>(u);
+    int j = 0;
+    while (j < B && __builtin_amdgcn_ballot_w64(u > 0x1p-54) != 0ull) {
+        if (j + DE_RUNW <= B) {
+            double uu[DE_RUNW], t[DE_RUNW];
+#pragma unroll
+            for (int k = 0; k < DE_RUNW; k++) { u = u * xr[j + k]; uu[k] = u; }
+            de_t2xw<true, DE_RUNW>(uu, t);
+#pragma unroll
+            for (int k = 0; k < DE_RUNW; k++) a = a * t[k];
+            j += DE_RUNW;
+        } else {
+            for (; j < B; j++) { u = u * xr[j]; a = a * de_t2<true>(u); }
+        }
+    }
+}
+
+// value of the fiber elements (left pivot pl | node i1 | node i2 | right pivot qr) of bond p, one per lane (pl, qr wave-uniform;
+// i1, i2 per lane), from the compact tables: tabulated factors by DPP row broadcasts, the bond-spanning tails by division, both
+// ended at the unit cut, everything in the reference's order.  All 64 lanes call it; dyn = the workgroup's dynamic LDS.
+__device__ __forceinline__ double dec_value(const DevProb &P, int g, int p, int first, int pl, int qr, int i1, int i2, double *dyn, int lane)
+{
+    const int m = P.d, A = p - 1, B = m - p - 1;
+    const int n1m = UNI(P.n[1]);
+    const double *nodes = P.par, *weights = P.par + n1m;                          // 0-based here
+    // LDS: UL[VS] | xl[VS] | wl[VS] | xr[VS] | wr[VS] | ring L[128] | ring R[128] | row counts
+    const int VS = ((m + 7) & ~7) + 8;
+    double *UL = dyn, *xl = UL + VS, *wl = xl + VS, *xr = wl + VS, *wr = xr + VS, *ringL = wr + VS, *ringR = ringL + 128;
+    int *cntL = (int *)(ringR + 128);
+    const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
+    const double *TLg = P.deTL + (size_t)g * tsz + (size_t)pl * NP, *TRg = P.deTR + (size_t)g * tsz + (size_t)qr * NP;
+    const double *ULg = P.deUL + ((size_t)g * P.RM + pl) * (m + 1);
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    for (int x = lane; x < A; x += 64) { const int ix = Lt[(size_t)x * P.RM + pl] - 1; xl[x] = nodes[ix]; wl[x] = weights[ix]; }
+    for (int x = lane; x < B; x += 64) { const int ix = Rt[(size_t)x * P.RM + qr] - 1; xr[x] = nodes[ix]; wr[x] = weights[ix]; }
+    for (int x = lane; x <= A; x += 64) UL[x] = ULg[x];
+    const int *CLg = P.deCL + ((size_t)g * P.RM + pl) * (m + 1), *CRg = P.deCR + ((size_t)g * P.RM + qr) * (m + 1);
+    for (int x = lane; x < A; x += 64) cntL[x] = CLg[x];
+    const int totL = UNI(CLg[m]), totR = UNI(CRg[m]);
+    const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
+    WStreamD<2> sl, sr;                                                // tabulated factors by DPP row broadcasts
+    sl.init(TLg, totL, ringL, lane);
+    sr.init(TRg, totR, ringR, lane);
+    __syncthreads();
+    // ---- pair product (test_crs_ising.f90:186-195), order of de_pairs_ctab ----
+    double a = 1.0;
+    const int i0 = UNI((int)ULg[m]), pre = UNI(CLg[m - 1]);
+    a = sl.chain_from_boundary(a, pre, lane);                          // rows 0 .. i0-1: they end inside the left pivot's dims
+    for (int i = i0; i <= A; i++) {                                    // the rows that reach the bond
+        if (i < A) a = sl.chain(a, UNI(cntL[i]), lane);
+        double u = UL[i];
+        u = u * x1; a = a * de_t2<true>(u);
+        de_run_cut(a, u, x2, xr, B);
+    }
+    de_run_cut(a, 1.0, x2, xr, B);                                     // i = A+1: starts after dim p
+    a = sr.chain_from_boundary(a, totR, lane);
+    // ---- b-part (id 2) and the weights (:197-218), order of de_finish.  v >= 1 and the running product vk never grows: once
+    //      vk <= 2^-54 every further v + vk returns v (half an ulp of v is at least 2^-53) -- the sums end there, bit for bit ----
+    const int id = P.ising_id;
+    double b = 0.0;
+    if (id == 2) {
+        double v = 1.0, ww = 1.0, vk = 1.0, wk = 1.0;
+        bool on = true;
+        for (int j = B - 1; j >= 0 && on; j--) { vk = vk * xr[j]; v = v + vk; on = __builtin_amdgcn_ballot_w64(vk > 0x1p-54) != 0ull; }
+        if (on) { vk = vk * x2; v = v + vk; vk = vk * x1; v = v + vk; on = __builtin_amdgcn_ballot_w64(vk > 0x1p-54) != 0ull; }
+        for (int j = A - 1; j >= 0 && on; j--) { vk = vk * xl[j]; v = v + vk; on = __builtin_amdgcn_ballot_w64(vk > 0x1p-54) != 0ull; }
+        on = true;
+        for (int j = 0; j < A && on; j++) { wk = wk * xl[j]; ww = ww + wk; on = __builtin_amdgcn_ballot_w64(wk > 0x1p-54) != 0ull; }
+        if (on) { wk = wk * x1; ww = ww + wk; wk = wk * x2; ww = ww + wk; on = __builtin_amdgcn_ballot_w64(wk > 0x1p-54) != 0ull; }
+        for (int j = 0; j < B && on; j++) { wk = wk * xr[j]; ww = ww + wk; on = __builtin_amdgcn_ballot_w64(wk > 0x1p-54) != 0ull; }
+        b = 1.0 / (v * ww);
+    }
+    double f = (id == 2) ? 2 * a * b : 2 * a;
+    for (int j = 0; j < A; j++) f = f * wl[j];
+    f = f * w1; f = f * w2;
+    for (int j = 0; j < B; j++) f = f * wr[j];
+    return f;
+}
+// lottery candidates of the compact-table path: one wave per candidate (the lanes work redundantly: the value is a dependent chain)
+// grid = (lot_max, groups), 64 threads; candidates from P.lotc (k_lottery phase 1), values to P.lotf (phase 2)
+__global__ __launch_bounds__(64) void k_lottery_eval_dec(DevProb P)
+{
+    extern __shared__ __align__(16) double dyn[];
+    const int g = blockIdx.y, lane = threadIdx.x, il = blockIdx.x;
+    const GroupState &gs = P.gs[g];
+    const StepState &st = gs.S[0];
+    if (!UNI(st.active)) return;
+    const int nlot = UNI(st.r0) + UNI(st.n1) + UNI(st.n2) + UNI(st.r2);
+    if (il >= nlot) return;
+    const int *c_ = P.lotc + ((size_t)g * P.lot_max + il) * 4;
+    const int i = UNI(c_[0]), j = UNI(c_[1]), k = UNI(c_[2]), q = UNI(c_[3]);
+    const double f = dec_value(P, g, UNI(st.p), UNI(gs.first), i - 1, q - 1, j - 1, k - 1, dyn, lane);
+    if (lane == 0) P.lotf[(size_t)g * P.lot_max + il] = f;
+}
+
+// The same kernel on the COMPACT tables of k_de_ctables (P.de_cut: all nodes in [0,1]): every row of the pair triangle ends at the
+// unit cut -- its tabulated part after CL[i] factors, its bond-spanning tail where the lanes' running products have all reached
+// 2^-54 (a lane that is already there multiplies factors that are exactly 1).  ~12 % of the factors of D_256 are left, in the
+// reference's order: the same bits.  LDS: as k_halfstep_de + the row counts.
+__global__ __launch_bounds__(64) void k_halfstep_dec(DevProb P, int h, int dir, int mode)
+{
+    extern __shared__ __align__(16) double dyn[];
+    __shared__ StepState cur;
+    const int g = blockIdx.y, lane = threadIdx.x, m = P.d;
+    GroupState &gs = P.gs[g];
+    if (lane == 0) { cur = gs.S[h]; resolve_state(cur, gs.Pt[(h + 1) & 1]); }
+    __syncthreads();
+    if (!cur.active || cur.done) { if (blockIdx.x == 0 && lane == 0) gs.S[h + 1] = cur; return; }
+    const bool iscol = (mode == 1 || mode == 2) ? (h == 0) : (((h + (dir == 2 ? 1 : 0)) & 1) == 0);    // :517,550
+    // what steers the control flow is made wave-uniform explicitly (values read from LDS / global memory are per-lane
+    // registers to the compiler: loop counters and branches would otherwise run on the vector unit)
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+    const int p = UNI(cur.p), r0 = UNI(cur.r0), r1 = UNI(cur.r1), r2 = UNI(cur.r2), n1 = UNI(cur.n1), n2 = UNI(cur.n2), first = UNI(gs.first);
+    const int c_ii = UNI(cur.ii), c_jj = UNI(cur.jj), c_kk = UNI(cur.kk), c_qq = UNI(cur.qq);
+    const int nf = iscol ? r0 * n1 : n2 * r2;
+    const int nv = iscol ? r0 : r2, nm = iscol ? n1 : n2, nch = (nm + 63) >> 6;
+    const int npart = nv * nch;
+    const int w = blockIdx.x;
+    const int crs = UNI(cur.crs) + 1;
+    const int havecol = UNI(cur.havecol) | (iscol ? 1 : 0), haverow = UNI(cur.haverow) | (iscol ? 0 : 1);
+    const int done = (mode == 1 || mode == 2) ? (h == 1) : (havecol && haverow && (crs >= 2 * P.piv));   // :534 / :567
+    const bool resid = (mode == 0) && !done;
+    if (w == 0 && lane == 0) {
+        StepState nx = cur;
+        nx.crs = crs; nx.havecol = havecol; nx.haverow = haverow; nx.done = done;
+        nx.pending = resid ? (iscol ? 1 : 2) : 0;
+        nx.npart = npart;
+        gs.S[h + 1] = nx;
+        if (mode != 2) gs.neval += nf;                                        // :527 / :560 / :509
+        gs.bytes_half += resid ? 8.0 * ((double)nf * r1 + r1 + 2.0 * nf) : 8.0 * nf;
+        gs.n_resid += resid ? 1 : 0;
+    }
+    if (w >= npart) return;
+    const int pv = w / nch, vmode = (w - pv * nch) * 64 + lane;        // varying pivot, mode index (0-based)
+    const bool live = vmode < nm;
+    const int pl = iscol ? pv : c_ii - 1, qr = iscol ? c_qq - 1 : pv;         // left / right pivot of this wave
+    const int i1 = iscol ? (live ? vmode : 0) : c_jj - 1, i2 = iscol ? c_kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
+    double a = dec_value(P, g, p, first, pl, qr, i1, i2, dyn, lane);
+    // ---- fiber store, amax, residual, arg-max: as k_halfstep, on the fiber's linear index t ----
+    const int u_ = iscol ? pv : vmode, v_ = iscol ? vmode : pv;        // col: (i, j) ; row: (k, q), 0-based
+    const int t = iscol ? (u_ + r0 * v_) : (u_ + n2 * v_);
+    if (live) (iscol ? P.acol : P.arow)[(size_t)g * P.RM * P.NM + t] = a;
+    const double mx = wave_max(live ? fabs(a) : 0.0);
+    if (lane == 0 && mode != 1) atomic_max_pos(&gs.amax, mx);          // :531 / :564 (the piv = 0 branch :492-513 does not touch amax)
+    if (resid) {
+        const double *Cp = core_ptr(P, P.col, g, p, first), *Wq = core_ptr(P, P.row, g, p + 1, first);
+        double bb = a, ab = -1.0; int bi = INT_MAX;
+        if (live) {
+            if (iscol) {   // dgemv 'n', alpha=-1 (:538): b += (-x_s) * col(:, s), x_s = row(p+1)(s, kk, qq)
+                const double *c = Cp + u_ + (size_t)P.RM * v_;
+                const double *xq = Wq + (c_kk - 1) + (size_t)P.NM * (c_qq - 1);
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) bb = bb + (-xq[P.SW * s]) * c[P.SS * s];
+            } else {       // dgemv 't', alpha=-1 (:571): b += -1 * sum_s row(s, kq) * x_s, x_s = col(p)(ii, jj, s)
+                const double *wv = Wq + u_ + (size_t)P.NM * v_;
+                const double *xc = Cp + (c_ii - 1) + (size_t)P.RM * (c_jj - 1);
+                double tt = 0.0;
+#pragma unroll 8
+                for (int s = 0; s < r1; s++) tt = tt + wv[P.SW * s] * xc[P.SS * s];
+                bb = bb + (-1.0) * tt;
+            }
+            ab = fabs(bb); bi = t;
+        }
+        wave_argmax(ab, bb, bi);
+        if (lane == 0) { Partial pr; pr.absmax = ab; pr.val = bb; pr.idx = bi; pr.pad = 0; gs.Pt[h & 1][w] = pr; }
+    }
+}
+#undef UNI
+
 // b-part (id 2) and weights (test_crs_ising.f90:197-218) from per-dimension value arrays xv / wv (0-based dims)
 __device__ __forceinline__ double de_finish_vals(int id, double a, int m, const double *xv, const double *wv)
 {

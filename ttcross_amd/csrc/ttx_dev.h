@@ -105,6 +105,8 @@ struct DevProb {
     double *deTL, *deUL, *deTR;  // Ising D/E: per-bond pair-factor tables [G][RM][de_npair], [G][RM][d+1], [G][RM][de_npair] (k_de_tables)
     int de_npair;
     int de_unit;                 // all nodes of par lie in [0,1]: the exact short division fdiv_unit applies
+    int de_cut;                  // ... and the tables are the COMPACT ones of k_de_ctables: every row of the pair triangle ends at the unit cut
+    int *deCL, *deCR;            // [G][RM][d+1]: entries per row of a pivot's compact table; [..][d] = their total
     const double *auxT;        // mvn: inv_cov transposed, auxT[j + d*i] = inv_cov(i,j) (same values, row walk contiguous)
     const double *quadw;       // [d+1][NM] padded, 1-based core index
     double *arg, *col, *row;   // [G][NC][CS]

@@ -429,25 +429,35 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
             }
         }
     }
-    if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && !P.arith && !(getenv("TTX_DE_TABLES") && atoi(getenv("TTX_DE_TABLES")) == 0)) {
+    const bool de_lane = getenv("TTX_DE_LANE") && atoi(getenv("TTX_DE_LANE")) == 1;
+    if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && !P.arith && de_lane) {
+        // one fiber element per lane, every pair by division, rows ended at the unit cut (f_ising_de with `unit`): no tables, no teams
+        P.de_unit = 1;
+        for (int j = 0; j < cfg->n[0]; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) P.de_unit = 0;
+    }
+    if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && !P.arith && !de_lane && !(getenv("TTX_DE_TABLES") && atoi(getenv("TTX_DE_TABLES")) == 0)) {
         P.de_npair = d * (d + 1) / 2;
         A_(dev_alloc(h, &P.deTL, G * (size_t)P.de_npair * RM)); A_(dev_alloc(h, &P.deTR, G * (size_t)P.de_npair * RM));
         A_(dev_alloc(h, &P.deUL, G * (size_t)(d + 1) * RM));
         P.de_unit = 1;                  // nodes in [0,1]: every running product stays in [0,1] and fdiv_unit is exact
         for (int j = 0; j < cfg->n[0]; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) P.de_unit = 0;
         if (getenv("TTX_DE_FASTDIV") && atoi(getenv("TTX_DE_FASTDIV")) == 0) P.de_unit = 0;
+        // nodes in [0,1]: compact tables, every row of the pair triangle ends at the unit cut (k_de_ctables, k_halfstep_dec; same bits).
+        // TTX_DE_CUT=0: the full tables and the kernels of round 2 (wave teams, row-wise lottery)
+        P.de_cut = (P.de_unit && !(getenv("TTX_DE_CUT") && atoi(getenv("TTX_DE_CUT")) == 0)) ? 1 : 0;
+        if (P.de_cut) { A_(dev_alloc(h, &P.deCL, G * (size_t)(d + 1) * RM)); A_(dev_alloc(h, &P.deCR, G * (size_t)(d + 1) * RM)); }
         h->de_slots = (int)RM * ((NM + 63) / 64);
-        h->lds_de = sizeof(double) * (5 * (size_t)(((d + 7) & ~7) + 8) + 256);
+        h->lds_de = sizeof(double) * (5 * (size_t)(((d + 7) & ~7) + 8) + 256) + (P.de_cut ? sizeof(int) * (size_t)(((d + 7) & ~7) + 8) : 0);
         h->de_v2 = cfg->pivoting >= 0 && h->de_slots <= TTX_MAXPART && h->lds_de <= 150 * 1024 &&
                    !(getenv("TTX_DE_V2") && atoi(getenv("TTX_DE_V2")) == 0);
         h->lds_det = sizeof(double) * det_lds_doubles(d, 3);
         h->lds_det6 = sizeof(double) * det_lds_doubles(d, 1);
         if (getenv("TTX_DE_TEAM6_UNITS")) h->de_team6_units = atoi(getenv("TTX_DE_TEAM6_UNITS"));
-        h->de_team = h->de_v2 && h->lds_det <= 150 * 1024 && !(getenv("TTX_DE_TEAM") && atoi(getenv("TTX_DE_TEAM")) == 0);
+        h->de_team = h->de_v2 && !P.de_cut && h->lds_det <= 150 * 1024 && !(getenv("TTX_DE_TEAM") && atoi(getenv("TTX_DE_TEAM")) == 0);
         if (getenv("TTX_DE_TEAM_UNITS")) h->de_team_units = atoi(getenv("TTX_DE_TEAM_UNITS"));
         if (getenv("TTX_DE_TEST_FAULT")) h->de_test_fault = atoi(getenv("TTX_DE_TEST_FAULT"));
         h->lds_de5 = sizeof(double) * de5_lds_doubles(d);
-        h->de_v5 = h->de_v2 && de5_fits(d) && h->lds_de5 <= 150 * 1024 && getenv("TTX_DE_V5") && atoi(getenv("TTX_DE_V5")) == 1;
+        h->de_v5 = h->de_v2 && !P.de_cut && de5_fits(d) && h->lds_de5 <= 150 * 1024 && getenv("TTX_DE_V5") && atoi(getenv("TTX_DE_V5")) == 1;
     }
     if (cfg->fun_id == TTX_FUN_MVN) {
         std::vector<double> t((size_t)d * d);
@@ -664,8 +674,8 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
             P.lotc = lcd; P.lotf = lf;
             // candidates and boundary corners by the row-wise wave evaluator (ttx_de.h); TTX_LOTTERY_WAVE=0: one lane per element
             h->lds_der = sizeof(double) * de_rows_lds_doubles(d);
-            h->lot_wave = h->de_v2 && h->lds_der <= 150 * 1024 && !(getenv("TTX_LOTTERY_WAVE") && atoi(getenv("TTX_LOTTERY_WAVE")) == 0);
-            P.bnd_wave = h->lot_wave;
+            h->lot_wave = h->de_v2 && !P.de_cut && h->lds_der <= 150 * 1024 && !(getenv("TTX_LOTTERY_WAVE") && atoi(getenv("TTX_LOTTERY_WAVE")) == 0);
+            P.bnd_wave = h->lot_wave || (P.de_cut && h->de_v2 && h->lds_der <= 150 * 1024);    // boundary corners by one wave per corner
             h->lot_rows = h->lot_wave ? ((getenv("TTX_LOTTERY_ROWS") && atoi(getenv("TTX_LOTTERY_ROWS")) == 2) ? 2 : 1) : 0;
         }
     }
@@ -1217,6 +1227,10 @@ static int run_impl(ttx_engine *h)
         if (h->fused && (rc = ensure_lds(reinterpret_cast<const void *>(k_sweep_fused), h->lds_fused, a_fused))) return rc;
         if (h->cluster && (rc = ensure_lds(reinterpret_cast<const void *>(k_sweep_cluster), h->lds_cluster, a_cluster))) return rc;
         static size_t a_de0 = 0, a_de1 = 0;
+        static size_t a_dec = 0;
+        static size_t a_dlc = 0;
+        if (h->de_v2 && P.de_cut && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_dec), h->lds_de, a_dec)) ||
+                                     (rc = ensure_lds(reinterpret_cast<const void *>(k_lottery_eval_dec), h->lds_de, a_dlc)))) return rc;
         if (h->de_v2 && ((rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<true>), h->lds_de, a_de0)) ||
                          (rc = ensure_lds(reinterpret_cast<const void *>(k_halfstep_de<false>), h->lds_de, a_de1)))) return rc;
         static size_t a_dt0 = 0, a_dt1 = 0;
@@ -1323,7 +1337,8 @@ static int run_impl(ttx_engine *h)
         for (int pp = 1; pp <= h->nbmax && !h->fused && !h->cluster; pp++) {
             if (P.deTL) {   // Ising D/E: pair factors of this bond that do not span it (shared by all elements through a pivot)
                 KScope ks(h, TTX_K_OTHER);
-                hipLaunchKernelGGL(k_de_tables, dim3((2 * (d + 1) * h->RM + 255) / 256, G), dim3(256), 0, st, P, dir, pp);
+                if (P.de_cut) hipLaunchKernelGGL(k_de_ctables, dim3(2 * h->RM, G), dim3(256), sizeof(double) * (size_t)(d + 2), st, P, dir, pp);
+                else hipLaunchKernelGGL(k_de_tables, dim3((2 * (d + 1) * h->RM + 255) / 256, G), dim3(256), 0, st, P, dir, pp);
             }
             const bool fastk = P.arith && (FUN == FUN_MVN || (FUN == FUN_ISING && P.ising_id != 1));
             if (fastk && !P.fpersist) {    // TTX_ARITH=fast, mvn: per-pivot tables of this bond step (ttx_fast.h; Ising D/E keeps its tables per bond)
@@ -1338,6 +1353,12 @@ static int run_impl(ttx_engine *h)
                     KScope ks(h, TTX_K_LOTTERY, 3);
                     hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 1);
                     hipLaunchKernelGGL(k_lottery_eval_mvn, dim3(P.lot_max, G), dim3(64), h->lds_mvn, st, P);
+                    hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 2);
+                } else if (FUN == FUN_ISING && P.de_cut && h->de_v2 && P.lotc) {
+                    // compact tables: one wave per candidate between the drawing and the scoring launch
+                    KScope ks(h, TTX_K_LOTTERY, 3);
+                    hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 1);
+                    hipLaunchKernelGGL(k_lottery_eval_dec, dim3(P.lot_max, G), dim3(64), h->lds_de, st, P);
                     hipLaunchKernelGGL(k_lottery<FUN>, dim3(1, G), dim3(512), h->lds_lot, st, P, dir, pp, h->lot_vals, 2);
                 } else if (FUN == FUN_ISING && h->lot_wave) {
                     KScope ks(h, TTX_K_LOTTERY, 3);
@@ -1375,7 +1396,8 @@ static int run_impl(ttx_engine *h)
                         } else if (h->de_v5) {
                             if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de5<true>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
                             else hipLaunchKernelGGL(k_halfstep_de5<false>, dim3(h->de_slots, G), dim3(64 * DE5_W), h->lds_de5, st, P, hh, dir, h->mode);
-                        } else if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de<true>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
+                        } else if (P.de_cut) hipLaunchKernelGGL(k_halfstep_dec, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
+                        else if (P.de_unit) hipLaunchKernelGGL(k_halfstep_de<true>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
                         else hipLaunchKernelGGL(k_halfstep_de<false>, dim3(h->de_slots, G), dim3(64), h->lds_de, st, P, hh, dir, h->mode);
                     }
                 } else

@@ -43,9 +43,10 @@ __device__ __forceinline__ short *R_ptr(const DevProb &P, int g, int s, int firs
 // integrands (reference drivers' callbacks).  idx(s), s = 1..m, returns the 1-based mode index of dim s.
 // ------------------------------------------------------------------------------------------------
 template <class IDX>
-__device__ __forceinline__ double f_ising(int id, int m, int n1, const double *par, IDX idx)
+__device__ __forceinline__ double f_ising(int id, int m, int n1, const double *par, IDX idx, bool unit = false)
 {
-    // test_crs_ising.f90:176-218
+    // test_crs_ising.f90:176-218.  unit (all nodes in [0,1]): a row of the pair triangle ends where the running product has reached
+    // 2^-54 -- from there on every factor is EXACTLY 1 in fp64 (see f_ising_de), so leaving them out changes no bit
     const double *nodes = par - 1, *weights = par + n1 - 1;
     double a = 1.0, b = 0.0, f;
     if (id == 2 || id == 3) {
@@ -53,6 +54,7 @@ __device__ __forceinline__ double f_ising(int id, int m, int n1, const double *p
             double uij = 1.0;
             for (int j = i + 1; j <= m; j++) {
                 uij = uij * nodes[idx(j)];
+                if (unit && uij <= 0x1p-54) break;
                 double t = (uij - 1.0) / (uij + 1.0);
                 a = a * (t * t);
             }
@@ -169,7 +171,7 @@ template <int FUN, class IDX>
 __device__ __forceinline__ double eval_fun(const DevProb &P, const double *par, IDX idx, long slot = -1)
 {
     if (FUN == FUN_HOST) return f_host(P, idx, slot);
-    if (FUN == FUN_ISING) return (P.arith && P.ising_id != 1) ? f_ising_fast(P.ising_id, P.d, P.n[1], par, idx) : f_ising(P.ising_id, P.d, P.n[1], par, idx);
+    if (FUN == FUN_ISING) return (P.arith && P.ising_id != 1) ? f_ising_fast(P.ising_id, P.d, P.n[1], par, idx) : f_ising(P.ising_id, P.d, P.n[1], par, idx, P.de_unit != 0);
     if (FUN == FUN_STDNORM) return f_stdnorm(P.d, par, idx);
     return f_mvn(P.d, par, P.aux, P.mvn_norm, idx);
 }
@@ -370,11 +372,106 @@ __device__ __forceinline__ double de_pairs_tab(int m, const double *nodes, int A
     return a;
 }
 
+// ... the same walk that STOPS a row once the running product has reached the unit cut (`done()` is asked after every chunk
+// of 8 dims and after the explicit dims).  Exact mode with all nodes in [0,1] (P.de_unit): the running product u_ij never grows,
+// and at u_ij <= 2^-54 the factor is EXACTLY 1 in fp64 -- u-1 rounds to -1, u+1 to 1, (-1/1)^2 = 1, a*1 = a -- so the rest of
+// the row changes no bit of the product (the factors between the cut and the end of its chunk are multiplied: they are 1 too).
+// At the drivers' Gauss-Legendre nodes a row ends after ~16 dims: 12 % of the 32 640 pairs of D_256 are left
+// (oracle: ttxo_set_unit_skip, tests/test_oracle_golden.py::test_unit_skip_changes_no_bit).
+template <class STEP, class DONE>
+__device__ __forceinline__ bool seg_range_cut(const short *p, int lo, int hi, const double *tab, STEP step, DONE done)
+{
+    for (int c = lo & ~7; c < hi; c += 8) {
+        Short8 ix = ld8(p + c); double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = tab[ix.v[k]];
+        if (c >= lo && c + 8 <= hi) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) step(x[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (c + k >= lo && c + k < hi) step(x[k]);
+        }
+        if (done()) return true;
+    }
+    return false;
+}
+template <int NS, class STEP, class DONE>
+__device__ __forceinline__ void dims_asc_cut(const short *pa, int A, int s1, int s2, const short *pb, int m, const double *tab,
+                                             int jlo, int jhi, STEP step, DONE done)
+{
+    if (jlo > jhi) return;
+    const int a1 = jhi < A ? jhi : A;
+    if (jlo <= a1 && seg_range_cut(pa, jlo - 1, a1, tab, step, done)) return;
+    if (jlo <= A + 1 && A + 1 <= jhi) step(tab[s1]);
+    if (NS == 2 && jlo <= A + 2 && A + 2 <= jhi) step(tab[s2]);
+    if (done()) return;
+    const int b0 = jlo > A + NS + 1 ? jlo : A + NS + 1;
+    if (b0 <= jhi) seg_range_cut(pb, b0 - A - NS - 1, jhi - A - NS, tab, step, done);
+}
+// ... and from the COMPACT tables of k_de_ctables (P.de_cut: nodes in [0,1]): a row of the pair triangle is tabulated only up to the
+// unit cut (CLc[i] factors for start i; CLc[m] / CRc[m] = totals), ULc[i] = running product of the start's row through the last left
+// dim, or 0 when the row has ended inside the pivot's dims; the bond-spanning tail of a row ends at the cut as well.  Every factor
+// left out is exactly 1: the product is bit-identical to de_pairs_tab's and to the reference's.
+__device__ __forceinline__ double de_pairs_ctab(int m, const double *nodes, int A, const double *TLc, const int *CLc, const double *ULc,
+                                                int s1, int s2, const short *rix, int ro, const double *TRc, const int *CRc)
+{
+    const int B = m - A - 2;
+    const double x1 = nodes[s1], x2 = nodes[s2];
+    double a = 1.0, u = 1.0;
+    size_t pr = 0;
+    auto step = [&](double xv) { u = u * xv; a = a * de_t2<true>(u); };
+    auto done = [&]() { return u <= 0x1p-54; };
+    auto run = [&]() {                                  // the bond-spanning tail of a row from s2 on (u holds the product so far)
+        u = u * x2;
+        if (u <= 0x1p-54) return;
+        a = a * de_t2<true>(u);
+        seg_range_cut(rix, ro, ro + B, nodes, step, done);
+    };
+    // one run of tabulated factors in order, 16 loads in flight ahead of the 16 dependent multiplies
+    auto stream = [&](const double *T, int n) {
+        int t = 0;
+        for (; t + 16 <= n; t += 16) {
+            double f[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) f[k] = T[t + k];
+#pragma unroll
+            for (int k = 0; k < 16; k++) a = a * f[k];
+        }
+        for (; t < n; t++) a = a * T[t];
+    };
+    const int i0 = (int)ULc[m], pre = CLc[m - 1];       // rows before i0 end inside the left pivot's dims
+    stream(TLc, pre);
+    pr = pre;
+    for (int i = i0; i <= A; i++) {
+        const int cnt = (i < A) ? CLc[i] : 0;
+        stream(TLc + pr, cnt);
+        pr += cnt;
+        u = ULc[i] * x1;
+        if (u > 0x1p-54) { a = a * de_t2<true>(u); run(); }
+    }
+    u = 1.0; run();                                     // i = A+1: starts after s1
+    stream(TRc, CRc[m]);                                // i >= A+2: pairs inside the right pivot's dims
+    return a;
+}
+
 template <int NS>
-__device__ __forceinline__ double f_ising_de(int id, int m, int n1, const double *par, const short *pa, int A, int s1, int s2, const short *pb)
+__device__ __forceinline__ double f_ising_de(int id, int m, int n1, const double *par, const short *pa, int A, int s1, int s2, const short *pb, bool unit = false)
 {
     const double *nodes = par - 1;
     double a = 1.0;
+    if (unit) {
+        for (int i = 0; i <= m; i++) {
+            double uij = 1.0;
+            const int jlo = i + 1, jhi = m;
+            if (jlo > jhi) continue;
+            dims_asc_cut<NS>(pa, A, s1, s2, pb, m, nodes, jlo, jhi, [&](double xv) {
+                uij = uij * xv;
+                a = a * de_t2<true>(uij);
+            }, [&]() { return uij <= 0x1p-54; });
+        }
+        return de_finish<NS>(id, a, m, n1, par, pa, A, s1, s2, pb);
+    }
     for (int i = 0; i <= m; i++) {                                   // :186-195
         double uij = 1.0;
         const int jlo = i + 1, jhi = m;
@@ -465,7 +562,7 @@ __device__ __forceinline__ double eval_src4(const DevProb &P, const double *par,
 {
     if (FUN == FUN_ISING && P.ising_id == 1) return f_ising_c4(P.d, P.n[1], par, S);
     if (FUN == FUN_ISING && P.arith) return f_ising_fast(P.ising_id, P.d, P.n[1], par, S);
-    if (FUN == FUN_ISING) return f_ising_de<2>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.s1, S.s2, S.pb);
+    if (FUN == FUN_ISING) return f_ising_de<2>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.s1, S.s2, S.pb, P.de_unit != 0);
     return eval_fun<FUN>(P, par, S, slot);
 }
 
@@ -574,7 +671,7 @@ __device__ __forceinline__ double eval_src3(const DevProb &P, const double *par,
 {
     if (ALIGNED && FUN == FUN_ISING && P.ising_id == 1) return f_ising_c3(P.d, P.n[1], par, S);
     if (ALIGNED && FUN == FUN_ISING && P.arith) return f_ising_fast(P.ising_id, P.d, P.n[1], par, S);
-    if (ALIGNED && FUN == FUN_ISING) return f_ising_de<1>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.self, 0, S.pb);
+    if (ALIGNED && FUN == FUN_ISING) return f_ising_de<1>(P.ising_id, P.d, P.n[1], par, S.pa, S.A, S.self, 0, S.pb, P.de_unit != 0);
     return eval_fun<FUN>(P, par, S, slot);
 }
 
@@ -1098,6 +1195,64 @@ __global__ __launch_bounds__(256) void k_de_tables(DevProb P, int dir, int pp)
     }
 }
 
+// Ising D / E with all nodes in [0,1] (P.de_cut): the COMPACT tables.  One workgroup per pivot of the two sets of the bond step
+// (left pivots of bond p-1, right pivots of bond p+1).  Row i of a pivot (start at its dim i+1): the factors ((u-1)/(u+1))^2 of
+// u = x_{i+1} ... x_j, j = i+1, i+2, ..., while u > 2^-54 -- at u <= 2^-54 the factor is exactly 1 and, u being non-increasing, so is
+// every later one of the row.  A pivot's rows are CONTIGUOUS in the order in which an element through that pivot multiplies
+// them; CL / CR[i] = entries of row i, [m] = their total; UL[i] = the running product of row i through the pivot's last dim when
+// the row gets that far, else 0 (UL[A] = 1: the row that starts behind the pivot); UL[m] = first such row i0 (all later ones get
+// that far too), CL[m-1] = entries of the rows before it.  ~12 % of the full triangle at D_256.
+// grid = (2 RM, groups), 256 threads, dynamic LDS d doubles.
+__global__ __launch_bounds__(256) void k_de_ctables(DevProb P, int dir, int pp)
+{
+    extern __shared__ __align__(16) double xs[];
+    __shared__ int s_w[4], s_carry;
+    const int g = blockIdx.y, m = P.d, RM = P.RM, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const GroupState &gs = P.gs[g];
+    const int first = gs.first, last = gs.last;
+    if (pp > last - first + 1) return;
+    const int p = (dir == 1) ? first + pp - 1 : last + 1 - pp;
+    const int *r = P.r + (size_t)g * (m + 2);
+    const int side = (int)blockIdx.x / RM, c = (int)blockIdx.x % RM;
+    if (c >= (side == 0 ? r[p - 1] : r[p + 1])) return;
+    const int len = side == 0 ? p - 1 : m - p - 1;
+    const short *tab = side == 0 ? L_ptr(P, g, p - 1, first) : R_ptr(P, g, p + 1, first);
+    const size_t NP = (size_t)P.de_npair, tsz = NP * RM;
+    double *T = (side == 0 ? P.deTL : P.deTR) + (size_t)g * tsz + (size_t)c * NP;
+    int *C = (side == 0 ? P.deCL : P.deCR) + ((size_t)g * RM + c) * (m + 1);
+    double *UL = P.deUL + ((size_t)g * RM + c) * (m + 1);
+    __shared__ int s_i0, s_pre;
+    for (int k = tid; k < len; k += 256) xs[k] = P.par[tab[(size_t)k * RM + c] - 1];
+    if (tid == 0) { s_carry = 0; s_i0 = len; s_pre = -1; }
+    __syncthreads();
+    for (int base = 0; base < len; base += 256) {
+        const int i = base + tid;
+        int cnt = 0; double u = 1.0;
+        if (i < len) for (int j = i; j < len; j++) { u = u * xs[j]; if (u <= 0x1p-54) break; cnt++; }
+        // exclusive scan of cnt over the workgroup
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+        if (lane == 63) s_w[wv] = inc;
+        if (i < len && cnt == len - i) atomicMin(&s_i0, i);          // the row gets through the pivot's last dim: it and all later ones span the bond
+        __syncthreads();
+        int off = s_carry + inc - cnt;
+        for (int w = 0; w < wv; w++) off += s_w[w];
+        if (i == s_i0 && i < len) s_pre = off;
+        if (i < len) {
+            C[i] = cnt;
+            if (side == 0) UL[i] = (cnt == len - i) ? u : 0.0;
+            double uu = 1.0;
+            for (int t = 0; t < cnt; t++) { uu = uu * xs[i + t]; T[off + t] = de_t2<true>(uu); }
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    // rows 0 .. i0-1 end inside the pivot's dims: their C[m-1] factors form one run without a bond-spanning tail in between
+    if (tid == 0) { C[m] = s_carry; C[m - 1] = (s_pre >= 0) ? s_pre : s_carry; if (side == 0) { UL[len] = 1.0; UL[m] = (double)s_i0; } }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_lottery: lottery2 candidates, their values and residuals, start pivot (lib/dmrgg.f90:410-484)
 // one block per group
@@ -1243,7 +1398,9 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
             const double *TL = P.deTL + (size_t)g * tsz + (size_t)(i - 1) * NP, *UL = P.deUL + ((size_t)g * P.RM + (i - 1)) * (m + 1);
             const double *TR = P.deTR + (size_t)g * tsz + (size_t)(q - 1) * NP;
             const short *pa_ = LT + (size_t)(i - 1) * VS, *pb_ = RT + (size_t)(q - 1) * VS;
-            const double ap = P.de_unit ? de_pairs_tab<true>(m, par - 1, p - 1, TL, UL, j, k, pb_, 0, TR)
+            const double ap = P.de_cut ? de_pairs_ctab(m, par - 1, p - 1, TL, P.deCL + ((size_t)g * P.RM + (i - 1)) * (m + 1), UL, j, k, pb_, 0, TR,
+                                                       P.deCR + ((size_t)g * P.RM + (q - 1)) * (m + 1))
+                            : P.de_unit ? de_pairs_tab<true>(m, par - 1, p - 1, TL, UL, j, k, pb_, 0, TR)
                                         : de_pairs_tab<false>(m, par - 1, p - 1, TL, UL, j, k, pb_, 0, TR);
             f = de_finish<2>(P.ising_id, ap, m, P.n[1], par, pa_, p - 1, j, k, pb_);
         } else {
@@ -1265,6 +1422,8 @@ __global__ __launch_bounds__(512) void k_lottery(DevProb P, int dir, int pp, int
     ma = block_max(ma, sha);
     block_argmax(ba, bv, bi, sha, shv, shi);
     if (nbl > 1) {
+        STAMP(gs, 0);   // (several blocks: block reductions; the fold of the partials is not stamped)
+        STAMP_END(gs, 0);
         // this block's partial, then the arrival counter; the last block folds all partials (blocks sit on different XCDs:
         // the fence pair makes the records visible across their L2s)
         LotPart *lp = P.lotp + (size_t)g * P.lot_nb;
@@ -1462,6 +1621,14 @@ __global__ __launch_bounds__(TTX_BLK) void k_halfstep(DevProb P, int h, int dir,
             const size_t NP = (size_t)P.de_npair, tsz = NP * P.RM;
             const double *TL = P.deTL + (size_t)g * tsz, *UL = P.deUL + (size_t)g * P.RM * (m + 1), *TR = P.deTR + (size_t)g * tsz;
             double pa_;
+            const int *CL = P.deCL + (size_t)g * P.RM * (m + 1), *CR = P.deCR + (size_t)g * P.RM * (m + 1);
+            if (P.de_cut) {
+                if (iscol) pa_ = de_pairs_ctab(m, par - 1, p - 1, TL + (size_t)u * NP, CL + (size_t)u * (m + 1), UL + (size_t)u * (m + 1), v + 1, cur.kk, fxs, 1,
+                                               TR + (size_t)(cur.qq - 1) * NP, CR + (size_t)(cur.qq - 1) * (m + 1));
+                else pa_ = de_pairs_ctab(m, par - 1, p - 1, TL + (size_t)(cur.ii - 1) * NP, CL + (size_t)(cur.ii - 1) * (m + 1), UL + (size_t)(cur.ii - 1) * (m + 1), cur.jj, u + 1,
+                                         vt + (size_t)v * VS, 0, TR + (size_t)v * NP, CR + (size_t)v * (m + 1));
+                a = iscol ? de_finish<1>(P.ising_id, pa_, m, n1m, par, vt + (size_t)u * VS, p - 1, v + 1, 0, fxs) : de_finish<1>(P.ising_id, pa_, m, n1m, par, fxs, p, u + 1, 0, vt + (size_t)v * VS);
+            } else
             if (iscol) {     // left pivot u varies, s1 = v+1, s2 = kk, right pivot qq fixed (fxs = [kk, right dims])
                 pa_ = de_pairs_tab<false>(m, par - 1, p - 1, TL + (size_t)u * NP, UL + (size_t)u * (m + 1), v + 1, cur.kk, fxs, 1, TR + (size_t)(cur.qq - 1) * NP);
                 a = de_finish<1>(P.ising_id, pa_, m, n1m, par, vt + (size_t)u * VS, p - 1, v + 1, 0, fxs);
@@ -2057,6 +2224,36 @@ __device__ __forceinline__ double de_corner_wave(const DevProb &P, const double 
     if (lane < 56) xv[m + lane] = 1.0;                      // the evaluator's running products read up to 47 columns past a row's end
     __builtin_amdgcn_wave_barrier();
     if (P.arith) return de_fast_point_wave(P.ising_id, m, xv, wv, lane);      // TTX_ARITH=fast (ttx_fast.h)
+    if (P.de_cut) {
+        // exact, rows ended at the unit cut (nodes in [0,1]): two rows of the pair triangle per step, one per half wave.  Lane t of a
+        // half forms u = x_i x_{i+1} ... x_{i+t} by its own left-to-right chain (the reference's running product), divides once, and
+        // the factors above the cut are multiplied into `a` in order through v_readlane; a row that is still above the cut after 32
+        // columns is finished by a plain chain (nodes close to 1).  The factors left out are exactly 1.
+        double a = 1.0;
+        const int hf = lane >> 5, t = lane & 31;
+        for (int i0 = 0; i0 < m; i0 += 2) {
+            const int i = i0 + hf;
+            double u = 1.0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) if (k <= t && i + k < m) u = u * xv[i + k];
+            const bool on = (i + t < m) && u > 0x1p-54;
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(on);
+            const int L0 = __builtin_popcount((unsigned)(mk & 0xffffffffull)), L1 = __builtin_popcount((unsigned)(mk >> 32));
+            const double f = on ? de_t2<true>(u) : 1.0;
+            const long long fb = __double_as_longlong(f), ub = __double_as_longlong(u);
+            auto rl = [&](long long v, int ln) { return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(v >> 32), ln) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)v, ln)); };
+            for (int h2 = 0; h2 < 2; h2++) {
+                const int L = h2 == 0 ? L0 : L1, row = i0 + h2;
+                if (row >= m) break;
+                for (int q = 0; q < L; q++) a = a * rl(fb, 32 * h2 + q);
+                if (L == 32 && row + 32 < m) {
+                    double uu = rl(ub, 32 * h2 + 31);
+                    for (int j = row + 32; j < m; j++) { uu = uu * xv[j]; if (uu <= 0x1p-54) break; a = a * de_t2<true>(uu); }
+                }
+            }
+        }
+        return de_finish_vals(P.ising_id, a, m, xv, wv);
+    }
     double a = 1.0;
     if (P.de_unit) for (int i = 0; i < m; i++) a = rows_span<true>(a, 1.0, xv + i, m - i, false, n);
     else for (int i = 0; i < m; i++) a = rows_span<false>(a, 1.0, xv + i, m - i, false, n);
