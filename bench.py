@@ -555,7 +555,8 @@ def main():
             f = w = None
             first = kname.split(" ")[0]
             for row in csv.reader(l for l in open(pm) if not l.startswith("#")):
-                if len(row) >= 6 and row[1].startswith(first):
+                nm = row[1].replace("void ", "") if len(row) >= 6 else ""
+                if nm == first or nm.startswith(first + "<") or nm.startswith(first + "("):
                     if row[2] == "FETCH_SIZE" and f is None:
                         f = float(row[5])
                     if row[2] == "WRITE_SIZE" and w is None:
