@@ -2227,31 +2227,49 @@ __device__ __forceinline__ double de_corner_wave(const DevProb &P, const double 
     if (P.de_cut) {
         // exact, rows ended at the unit cut (nodes in [0,1]): two rows of the pair triangle per step, one per half wave.  Lane t of a
         // half forms u = x_i x_{i+1} ... x_{i+t} by its own left-to-right chain (the reference's running product), divides once, and
-        // the factors above the cut are multiplied into `a` in order through v_readlane; a row that is still above the cut after 32
-        // columns is finished by a plain chain (nodes close to 1).  The factors left out are exactly 1.
+        // the factors above the cut go through LDS (the padding behind the two value rows) into `a` in order; a row that is still
+        // above the cut after 32 columns is finished by a plain chain (nodes close to 1).  The factors left out are exactly 1.
         double a = 1.0;
         const int hf = lane >> 5, t = lane & 31;
+        double *sf = (hf == 0 ? xv : wv) + m;                 // 32 factors per half (the rows are padded by 56 entries)
+        const double *sf0 = xv + m, *sf1 = wv + m;
         for (int i0 = 0; i0 < m; i0 += 2) {
             const int i = i0 + hf;
             double u = 1.0;
 #pragma unroll
-            for (int k = 0; k < 32; k++) if (k <= t && i + k < m) u = u * xv[i + k];
+            for (int k = 0; k < 32; k++) { const double xk = (i + k < m) ? xv[i + k] : 1.0; u = u * ((k <= t) ? xk : 1.0); }
             const bool on = (i + t < m) && u > 0x1p-54;
             const unsigned long long mk = __builtin_amdgcn_ballot_w64(on);
             const int L0 = __builtin_popcount((unsigned)(mk & 0xffffffffull)), L1 = __builtin_popcount((unsigned)(mk >> 32));
-            const double f = on ? de_t2<true>(u) : 1.0;
-            const long long fb = __double_as_longlong(f), ub = __double_as_longlong(u);
-            auto rl = [&](long long v, int ln) { return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(v >> 32), ln) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)v, ln)); };
-            for (int h2 = 0; h2 < 2; h2++) {
-                const int L = h2 == 0 ? L0 : L1, row = i0 + h2;
-                if (row >= m) break;
-                for (int q = 0; q < L; q++) a = a * rl(fb, 32 * h2 + q);
-                if (L == 32 && row + 32 < m) {
-                    double uu = rl(ub, 32 * h2 + 31);
-                    for (int j = row + 32; j < m; j++) { uu = uu * xv[j]; if (uu <= 0x1p-54) break; a = a * de_t2<true>(uu); }
+            __builtin_amdgcn_wave_barrier();
+            sf[t] = on ? de_t2<true>(u) : 1.0;
+            const double u31 = __shfl(u, 31 + 32 * 0, 64), u63 = __shfl(u, 63, 64);
+            __builtin_amdgcn_wave_barrier();
+            auto fold = [&](const double *sfp, int L) {         // eight LDS reads ahead of eight dependent multiplies; entries past L are 1.0
+                for (int c = 0; c < L; c += 8) {
+                    double f8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) f8[k] = sfp[c + k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) a = a * f8[k];
+                }
+            };
+            fold(sf0, L0);
+            if (L0 == 32 && i0 + 32 < m) {
+                double uu = u31;
+                for (int j = i0 + 32; j < m; j++) { uu = uu * xv[j]; if (uu <= 0x1p-54) break; a = a * de_t2<true>(uu); }
+            }
+            if (i0 + 1 < m) {
+                fold(sf1, L1);
+                if (L1 == 32 && i0 + 33 < m) {
+                    double uu = u63;
+                    for (int j = i0 + 33; j < m; j++) { uu = uu * xv[j]; if (uu <= 0x1p-54) break; a = a * de_t2<true>(uu); }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) { xv[m + lane] = 1.0; wv[m + lane] = 1.0; }
+        __builtin_amdgcn_wave_barrier();
         return de_finish_vals(P.ising_id, a, m, xv, wv);
     }
     double a = 1.0;
