@@ -1310,7 +1310,7 @@ static int run_impl(ttx_engine *h)
     int it = 0, strike = 0;
     bool ready = (it + 1 >= h->cfg.maxrank);
     const int nfb = (h->RM * h->NM + TTX_BLK - 1) / TTX_BLK;
-    const size_t lds_acc = sizeof(double) * (h->RM + 2);
+    const size_t lds_acc = sizeof(double) * std::max<size_t>(h->RM + 2, (size_t)std::min<int>(h->RM, 64) * std::min<int>(h->RM, 64));   // roles A/B: x[RM]; C/D: the staged LU
     // Pipelined mode (whole-sweep kernels, one process): the stopping rule also runs on the device (k_sweep_end), so
     // sweep it+1 is enqueued BEFORE the host has read the summary of sweep it -- the GPU never waits for the host.  When the rule fires, the one sweep that is already enqueued finds the stop flag and does nothing.
     // On a single GPU the per-sweep quadrature (only reported, never fed back) runs on its own stream next to the
@@ -2195,8 +2195,12 @@ static bool qr_own_launch(ttx_engine *h, const QrOwnShape &s, int rows, int n, i
     QRO(2, 1) QRO(4, 1) QRO(8, 1) QRO(2, 2) QRO(4, 2) QRO(8, 2) QRO(2, 4) QRO(4, 4) QRO(2, 8) QRO(4, 8)
 #undef QRO
     if (!fn) return false;
-    static std::map<const void *, size_t> lds_set;
-    if ((*rc_out = ensure_lds(fn, lds, lds_set[fn]))) return true;
+    {   // the dynamic-LDS limit set so far per instantiation (engines may be driven from several host threads)
+        static std::map<const void *, size_t> lds_set;
+        static std::mutex lds_mu;
+        std::lock_guard<std::mutex> lk(lds_mu);
+        if ((*rc_out = ensure_lds(fn, lds, lds_set[fn]))) return true;
+    }
     void *args[] = {&rows, &n, &rbs, &M, &ldm, &Q, &ldq, &R, &ldr, &rstep, &tau};
     hipError_t e = hipLaunchKernel(fn, dim3(P), dim3(s.nt), args, lds, h->stream);
     if (e != hipSuccess) *rc_out = fail(TTX_EHIP, "k_qr_own: %s", hipGetErrorString(e));

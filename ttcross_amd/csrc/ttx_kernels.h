@@ -1771,6 +1771,18 @@ __global__ __launch_bounds__(TTX_BLK) void k_accept(DevProb P, int H, int nA)
         const double *gI = inv_ptr(P, g, p - 1, first);
         double *Wp = core_ptr(P, P.row, g, p, first);
         double a = (tid < r0) ? acol[tid + r0 * j] : 0.0, tmp = 0.0, xf = 0.0;
+        if (r0 <= 64) {                               // one wave: the solve runs as a shuffle wavefront over the LDS-staged LU (as k_exch_boundary)
+            double *lu = dyn;
+            for (int x = tid; x < r0 * r0; x += TTX_BLK) lu[x] = gI[x];
+            __syncthreads();
+            if (tid < 64)
+                for (int s = 0; s < r0; s++) {
+                    const double cand = (s == 0) ? a : a + (-1.0) * tmp;
+                    const double xsv = __shfl(cand, s, 64);
+                    if (tid == s) xf = xsv;
+                    if (tid > s && tid < r0) tmp = tmp + xsv * lu[tid * tid + s];
+                }
+        } else
         for (int s = 0; s < r0; s++) {
             if (tid == s) { xf = a + (-1.0) * tmp; if (s == 0) xf = a; s_bc = xf; }
             __syncthreads();
@@ -1785,6 +1797,20 @@ __global__ __launch_bounds__(TTX_BLK) void k_accept(DevProb P, int H, int nA)
         const double *gI = inv_ptr(P, g, p + 1, first);
         double *Cq = core_ptr(P, P.col, g, p + 1, first);
         double y = (tid < r2) ? arow[k + n2 * tid] : 0.0;
+        if (r2 <= 64) {
+            double *lu = dyn;
+            for (int x = tid; x < r2 * r2; x += TTX_BLK) lu[x] = gI[x];
+            __syncthreads();
+            if (tid < 64) {
+                const double rdg = (tid < r2) ? 1.0 / lu[(tid + 1) * (tid + 1) - 1] : 0.0;
+                for (int s = 0; s < r2; s++) {
+                    const double cand = rdg * y;          // only lane s's product is used
+                    const double ys = __shfl(cand, s, 64);
+                    if (tid == s) y = ys;
+                    if (tid > s && tid < r2) y = y + (-lu[tid * tid + tid + s]) * ys;
+                }
+            }
+        } else
         for (int s = 0; s < r2; s++) {
             if (tid == s) { y = (1.0 / gI[(s + 1) * (s + 1) - 1]) * y; s_bc = y; }
             __syncthreads();
