@@ -1500,15 +1500,21 @@ static int run_impl(ttx_engine *h)
             if (int rc_ = xfer_neighbours(h)) return rc_;
             hipLaunchKernelGGL(k_exch_apply, dim3(G), dim3(256), (P.arith && P.fpersist) ? sizeof(double) * 4 * (d + 8) : 0, st, P);
         }
-        const size_t lds_f = sizeof(double) * ((size_t)h->RM * h->RM + 256 * (size_t)h->RM);
+        // threads (= columns) per workgroup: as many as fit the LDS next to the LU panel (256, 128 or 64); the columns of a core are
+        // spread over grid.z (at maxrank 64 the 256-thread staging did not fit: the kernels then ran out of L2 with one workgroup per
+        // core, 6 ms at D_256)
+        int ft = 256;
+        while (ft > 64 && sizeof(double) * ((size_t)h->RM * h->RM + (size_t)ft * h->RM) > 96 * 1024) ft >>= 1;
+        const size_t lds_f = sizeof(double) * ((size_t)h->RM * h->RM + (size_t)ft * h->RM);
         const int fl = lds_f <= 150 * 1024 ? 1 : 0;
+        const int fz = std::max(1, std::min(64, (h->NM * (int)h->RM + ft - 1) / ft));
         if (fl) {
             static size_t a_luar = 0, a_lual = 0;
             if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_fin_luar), lds_f, a_luar)) return rc_;
             if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_fin_lual), lds_f, a_lual)) return rc_;
         }
-        hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G), dim3(256), fl ? lds_f : 0, st, P, fl);
-        hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G), dim3(256), fl ? lds_f : 0, st, P, fl);
+        hipLaunchKernelGGL(k_fin_luar, dim3(h->NC, G, fz), dim3(ft), fl ? lds_f : 0, st, P, fl);
+        hipLaunchKernelGGL(k_fin_lual, dim3(h->NC, G, fz), dim3(ft), fl ? lds_f : 0, st, P, fl);
         return TTX_OK;
     };
     // host side of a finished sweep: record, tapes, log line, stopping rule (identical to k_sweep_end)

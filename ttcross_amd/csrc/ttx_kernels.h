@@ -833,6 +833,22 @@ __global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int n
     const int m = P.d, VSr = ((m + 7) & ~7) + 8;
     short *rows = (short *)(((size_t)(dyn + P.npar) + 15) & ~(size_t)15);
     short *row = rows + (size_t)tid * VSr;
+    if (FUN == FUN_ISING && P.arith && P.ising_id != 1 && ldsrows) {
+        // TTX_ARITH=fast, Ising D/E: one WAVE per sample (de_fast_point_wave: the lanes share the range ends).  A shifted diagonal with
+        // shift 0 repeats one node in every dimension; for a node close to 1 no range reaches the cut and one thread would walk the
+        // whole pair triangle (7 ms of the 220 ms of D_256 went into this kernel)
+        const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, n1m = P.n[1];
+        double *xv = (double *)rows + (size_t)wv * 2 * (m + 64), *wvv = xv + (m + 64);
+        for (int il = wv; il < nn * snum; il += nw) {
+            const int k = il % nn + 1, sft = il / nn;
+            __builtin_amdgcn_wave_barrier();
+            for (int x = lane; x < m; x += 64) { const int ix = (k - 1 + sft * x) % P.n[x + 1]; xv[x] = par[ix]; wvv[x] = par[n1m + ix]; }
+            __builtin_amdgcn_wave_barrier();
+            const double f = de_fast_point_wave(P.ising_id, m, xv, wvv, lane);
+            const double a = fabs(f);
+            if (lane == 0 && (a > ba || (a == ba && il < bi))) { ba = a; bv = f; bi = il; }
+        }
+    } else
     if (!ldsrows)                                             // rows do not fit the LDS: generic accessor
         for (int il = tid; il < nn * snum; il += blockDim.x) {
             DiagIdx ix{P.n, il % nn + 1, il / nn};
@@ -1972,27 +1988,30 @@ __global__ __launch_bounds__(256) void k_fin_luar(DevProb P, int lds)
     if (lds) {
         double *sg = fsh, *sc = fsh + (size_t)RM * RM;               // LU | columns as [t][thread]
         const int tid = threadIdx.x;
-        for (int x = tid; x < r0 * r0; x += blockDim.x) sg[x] = gL[x];
-        for (int x0 = 0; x0 < n * r1; x0 += blockDim.x) {
+        // the columns of a core are spread over the workgroups along grid.z (T = blockDim.x columns each): every column is independent
+        const int T = blockDim.x;
+        if ((int)(blockIdx.z * T) >= n * r1) return;
+        for (int x = tid; x < r0 * r0; x += T) sg[x] = gL[x];
+        for (int x0 = blockIdx.z * T; x0 < n * r1; x0 += gridDim.z * T) {
             const int x = x0 + tid;
             const bool on = x < n * r1;
             double *c = on ? A + (size_t)RM * (x % n) + P.SS * (x / n) : A;
             __syncthreads();
-            if (on) for (int t = 0; t < r0; t++) sc[t * 256 + tid] = c[t];
+            if (on) for (int t = 0; t < r0; t++) sc[t * T + tid] = c[t];
             __syncthreads();                                         // (also: sg complete before the first use)
             if (on) {
                 for (int t = 1; t < r0; t++) {
                     double tmp = 0.0;
 #pragma unroll 8
-                    for (int s = 0; s < t; s++) tmp = tmp + sc[s * 256 + tid] * sg[t * t + s];
-                    sc[t * 256 + tid] = sc[t * 256 + tid] + (-1.0) * tmp;
+                    for (int s = 0; s < t; s++) tmp = tmp + sc[s * T + tid] * sg[t * t + s];
+                    sc[t * T + tid] = sc[t * T + tid] + (-1.0) * tmp;
                 }
-                for (int t = 1; t < r0; t++) c[t] = sc[t * 256 + tid];
+                for (int t = 1; t < r0; t++) c[t] = sc[t * T + tid];
             }
         }
         return;
     }
-    for (int x = threadIdx.x; x < n * r1; x += blockDim.x) {       // one column (j,k) per thread, :1250
+    for (int x = blockIdx.z * blockDim.x + threadIdx.x; x < n * r1; x += gridDim.z * blockDim.x) {       // one column (j,k) per thread, :1250
         double *c = A + (size_t)RM * (x % n) + P.SS * (x / n);
         for (int t = 1; t < r0; t++) {
             double tmp = 0.0;
@@ -2015,27 +2034,29 @@ __global__ __launch_bounds__(256) void k_fin_lual(DevProb P, int lds)
     if (lds) {
         double *sg = fsh, *sc = fsh + (size_t)RM * RM;
         const int tid = threadIdx.x;
-        for (int x = tid; x < r1 * r1; x += blockDim.x) sg[x] = gU[x];
-        for (int x0 = 0; x0 < r0 * n; x0 += blockDim.x) {
+        const int T = blockDim.x;
+        if ((int)(blockIdx.z * T) >= r0 * n) return;
+        for (int x = tid; x < r1 * r1; x += T) sg[x] = gU[x];
+        for (int x0 = blockIdx.z * T; x0 < r0 * n; x0 += gridDim.z * T) {
             const int x = x0 + tid;
             const bool on = x < r0 * n;
             double *c = on ? A + (x % r0) + (size_t)RM * (x / r0) : A;
             __syncthreads();
-            if (on) for (int t = 0; t < r1; t++) sc[t * 256 + tid] = c[P.SS * t];
+            if (on) for (int t = 0; t < r1; t++) sc[t * T + tid] = c[P.SS * t];
             __syncthreads();
             if (on) {
                 for (int t = 0; t < r1; t++) {
-                    double y = sc[t * 256 + tid];
+                    double y = sc[t * T + tid];
 #pragma unroll 8
-                    for (int s = 0; s < t; s++) y = y + (-sg[t * t + t + s]) * sc[s * 256 + tid];
-                    sc[t * 256 + tid] = (1.0 / sg[(t + 1) * (t + 1) - 1]) * y;
+                    for (int s = 0; s < t; s++) y = y + (-sg[t * t + t + s]) * sc[s * T + tid];
+                    sc[t * T + tid] = (1.0 / sg[(t + 1) * (t + 1) - 1]) * y;
                 }
-                for (int t = 0; t < r1; t++) c[P.SS * t] = sc[t * 256 + tid];
+                for (int t = 0; t < r1; t++) c[P.SS * t] = sc[t * T + tid];
             }
         }
         return;
     }
-    for (int x = threadIdx.x; x < r0 * n; x += blockDim.x) {       // one row (i,j) per thread, :1251
+    for (int x = blockIdx.z * blockDim.x + threadIdx.x; x < r0 * n; x += gridDim.z * blockDim.x) {       // one row (i,j) per thread, :1251
         double *c = A + (x % r0) + (size_t)RM * (x / r0);
         for (int t = 0; t < r1; t++) {
             double y = c[P.SS * t];
