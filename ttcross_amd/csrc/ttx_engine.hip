@@ -1453,7 +1453,7 @@ static int run_impl(ttx_engine *h)
             if (nproc > 1) {
                 const size_t VSb = ((d + 7) & ~7) + 8;
                 const size_t lds_b = h->lds_par + 16 + sizeof(short) * 2 * VSb + sizeof(double) * (64 * 64 + 4) +
-                                     (P.bnd_wave ? sizeof(double) * (std::max<size_t>(2 * (size_t)de_rows_stride(d), 3 * (size_t)d + 2) + 8) : 0);    // D/E: two value rows; mvn: 3 d + 1 doubles
+                                     (P.bnd_wave ? sizeof(double) * (std::max<size_t>(2 * (size_t)de_rows_stride(d), 3 * (size_t)d + 2) + 8 + (P.de_cut ? 64 * 32 : 0)) : 0);    // D/E: two value rows; mvn: 3 d + 1 doubles
                 static size_t a_bnd = 0;
                 if (int rc_ = ensure_lds(reinterpret_cast<const void *>(k_exch_boundary<FUN>), lds_b, a_bnd)) return rc_;
                 if (int rc_ = EV([&](const DevProb &Q) { hipLaunchKernelGGL(k_exch_boundary<FUN>, dim3(2 * h->NM, G), dim3(TTX_BLK), lds_b, st, Q); })) return rc_;

@@ -2272,51 +2272,50 @@ __device__ __forceinline__ double de_corner_wave(const DevProb &P, const double 
     __builtin_amdgcn_wave_barrier();
     if (P.arith) return de_fast_point_wave(P.ising_id, m, xv, wv, lane);      // TTX_ARITH=fast (ttx_fast.h)
     if (P.de_cut) {
-        // exact, rows ended at the unit cut (nodes in [0,1]): two rows of the pair triangle per step, one per half wave.  Lane t of a
-        // half forms u = x_i x_{i+1} ... x_{i+t} by its own left-to-right chain (the reference's running product), divides once, and
-        // the factors above the cut go through LDS (the padding behind the two value rows) into `a` in order; a row that is still
-        // above the cut after 32 columns is finished by a plain chain (nodes close to 1).  The factors left out are exactly 1.
+        // exact, rows ended at the unit cut (nodes in [0,1]), 64 rows of the pair triangle per step: lane l walks row base+l left to
+        // right (its own running product, the reference's; one division per pair above the cut) and writes the factors, compacted
+        // by a wave prefix sum of the row lengths, to LDS; then the factors of the 64 rows go into `a` in order, sixteen LDS
+        // broadcasts ahead of sixteen dependent multiplies.  A row that is still above the cut after 32 pairs (nodes close to 1)
+        // sends the whole step down a plain serial walk.  The factors left out are exactly 1.
+        double *sf = wv + RSW;                               // 64 x 32 factors (the host sized the scratch for them)
         double a = 1.0;
-        const int hf = lane >> 5, t = lane & 31;
-        double *sf = (hf == 0 ? xv : wv) + m;                 // 32 factors per half (the rows are padded by 56 entries)
-        const double *sf0 = xv + m, *sf1 = wv + m;
-        for (int i0 = 0; i0 < m; i0 += 2) {
-            const int i = i0 + hf;
-            double u = 1.0;
+        for (int base = 0; base < m; base += 64) {
+            const int row = base + lane;
+            double u = 1.0, fr[32];
+            int L = 0; bool on = row < m;
 #pragma unroll
-            for (int k = 0; k < 32; k++) { const double xk = (i + k < m) ? xv[i + k] : 1.0; u = u * ((k <= t) ? xk : 1.0); }
-            const bool on = (i + t < m) && u > 0x1p-54;
-            const unsigned long long mk = __builtin_amdgcn_ballot_w64(on);
-            const int L0 = __builtin_popcount((unsigned)(mk & 0xffffffffull)), L1 = __builtin_popcount((unsigned)(mk >> 32));
-            __builtin_amdgcn_wave_barrier();
-            sf[t] = on ? de_t2<true>(u) : 1.0;
-            const double u31 = __shfl(u, 31 + 32 * 0, 64), u63 = __shfl(u, 63, 64);
-            __builtin_amdgcn_wave_barrier();
-            auto fold = [&](const double *sfp, int L) {         // eight LDS reads ahead of eight dependent multiplies; entries past L are 1.0
-                for (int c = 0; c < L; c += 8) {
-                    double f8[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) f8[k] = sfp[c + k];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) a = a * f8[k];
-                }
-            };
-            fold(sf0, L0);
-            if (L0 == 32 && i0 + 32 < m) {
-                double uu = u31;
-                for (int j = i0 + 32; j < m; j++) { uu = uu * xv[j]; if (uu <= 0x1p-54) break; a = a * de_t2<true>(uu); }
+            for (int c = 0; c < 32; c++) {
+                fr[c] = 1.0;
+                if (on && row + c < m) { u = u * xv[row + c]; if (u > 0x1p-54) { fr[c] = de_t2<true>(u); L = c + 1; } else on = false; }
+                else on = false;
             }
-            if (i0 + 1 < m) {
-                fold(sf1, L1);
-                if (L1 == 32 && i0 + 33 < m) {
-                    double uu = u63;
-                    for (int j = i0 + 33; j < m; j++) { uu = uu * xv[j]; if (uu <= 0x1p-54) break; a = a * de_t2<true>(uu); }
+            const bool lng = (L == 32) && (row + 32 < m) && (u > 0x1p-54);
+            if (__builtin_amdgcn_ballot_w64(lng) != 0ull) {                 // rare: serial walk of these rows by every lane
+                const int rend = (base + 64 < m) ? base + 64 : m;
+                for (int r = base; r < rend; r++) {
+                    double uu = 1.0;
+                    for (int j = r; j < m; j++) { uu = uu * xv[j]; if (uu <= 0x1p-54) break; a = a * de_t2<true>(uu); }
                 }
+                continue;
             }
+            int inc = L;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+            const int off = inc - L, total = __shfl(inc, 63, 64);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 32; c++) if (c < L) sf[off + c] = fr[c];
+            __builtin_amdgcn_wave_barrier();
+            int t = 0;
+            for (; t + 16 <= total; t += 16) {
+                double f16[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) f16[k] = sf[t + k];
+#pragma unroll
+                for (int k = 0; k < 16; k++) a = a * f16[k];
+            }
+            for (; t < total; t++) a = a * sf[t];
         }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 32) { xv[m + lane] = 1.0; wv[m + lane] = 1.0; }
-        __builtin_amdgcn_wave_barrier();
         return de_finish_vals(P.ising_id, a, m, xv, wv);
     }
     double a = 1.0;
