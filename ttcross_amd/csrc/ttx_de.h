@@ -448,6 +448,35 @@ __global__ __launch_bounds__(64) void k_lottery_eval_dec(DevProb P)
     if (lane == 0) P.lotf[(size_t)g * P.lot_max + il] = f;
 }
 
+// lottery candidates of the unit-cut path: one wave per candidate, no tables -- a candidate is ONE multi-index, whose pair product a
+// wave forms row-parallel (de_pairs_point_wave_cut: every lane walks a row of the triangle, the factors above the cut are then
+// multiplied in order out of LDS); b-part and weights by de_finish_vals.  The chain of ~3 900 ordered multiplies is what remains.
+// grid = (lot_max, groups), 64 threads, dynamic LDS 2 (m + 64) + 2048 doubles; candidates from P.lotc (k_lottery phase 1),
+// values to P.lotf (phase 2)
+__global__ __launch_bounds__(64) void k_lottery_eval_decp(DevProb P)
+{
+    extern __shared__ __align__(16) double dyn[];
+    const int g = blockIdx.y, lane = threadIdx.x, il = blockIdx.x, m = P.d;
+    const GroupState &gs = P.gs[g];
+    const StepState &st = gs.S[0];
+    if (!UNI(st.active)) return;
+    const int nlot = UNI(st.r0) + UNI(st.n1) + UNI(st.n2) + UNI(st.r2);
+    if (il >= nlot) return;
+    const int *c_ = P.lotc + ((size_t)g * P.lot_max + il) * 4;
+    const int ci = UNI(c_[0]) - 1, cj = UNI(c_[1]) - 1, ck = UNI(c_[2]) - 1, cq = UNI(c_[3]) - 1;
+    const int p = UNI(st.p), first = UNI(gs.first), A = p - 1, n1m = UNI(P.n[1]);
+    double *xv = dyn, *wv = dyn + (m + 64), *sf = wv + (m + 64);
+    const double *nodes = P.par, *weights = P.par + n1m;
+    const short *Lt = L_ptr(P, g, p - 1, first), *Rt = R_ptr(P, g, p + 1, first);
+    for (int x = lane; x < m; x += 64) {
+        const int ix = (x < A) ? Lt[(size_t)x * P.RM + ci] - 1 : (x == A) ? cj : (x == A + 1) ? ck : Rt[(size_t)(x - A - 2) * P.RM + cq] - 1;
+        xv[x] = nodes[ix]; wv[x] = weights[ix];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double f = de_finish_vals(P.ising_id, de_pairs_point_wave_cut(m, xv, sf, lane), m, xv, wv);
+    if (lane == 0) P.lotf[(size_t)g * P.lot_max + il] = f;
+}
+
 // The same kernel on the COMPACT tables of k_de_ctables (P.de_cut: all nodes in [0,1]): every row of the pair triangle ends at the
 // unit cut -- its tabulated part after CL[i] factors, its bond-spanning tail where the lanes' running products have all reached
 // 2^-54 (a lane that is already there multiplies factors that are exactly 1).  ~12 % of the factors of D_256 are left, in the

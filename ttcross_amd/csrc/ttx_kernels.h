@@ -2256,28 +2256,14 @@ __global__ __launch_bounds__(256) void k_exch_max_apply(DevProb P, int from_recv
 template <bool FAST> __device__ __forceinline__ double rows_span(double a, double u0, const double *xs, int L, bool neutral0, int n);
 __host__ __device__ inline int de_rows_stride(int m);
 __device__ __forceinline__ double de_finish_vals(int id, double a, int m, const double *xv, const double *wv);
-// corner entry of the Ising D / E integrands by the first wave of the block: multi-index = rowA (dims 1..p-1) | self | rowB.
-// Every pair by division with the row-wise evaluator of the lottery (ttx_de.h): the four DPP rows of the wave work on the same
-// element (lane n of a row = column n of a 16-column chunk of the pair triangle), the result is identical in all lanes.
-__device__ __forceinline__ double de_corner_wave(const DevProb &P, const double *par, const short *rowA, int p, int self, const short *rowB,
-                                                 double *scratch, int lane)
+// Pair product a = prod ((u_ij-1)/(u_ij+1))^2 of ONE multi-index by one wave, exact, rows ended at the unit cut (nodes in [0,1]); xv = its m
+// node values in LDS, sf = 64 x 32 doubles of LDS.  64 rows of the pair triangle per step: lane l walks row base+l left to right (its
+// own running product, the reference's; one division per pair above the cut) and writes the factors, compacted by a wave prefix sum
+// of the row lengths, to LDS; then the factors of the 64 rows go into `a` in order, sixteen LDS broadcasts ahead of sixteen dependent
+// multiplies.  A row that is still above the cut after 32 pairs (nodes close to 1) sends the whole step down a plain serial walk.
+// The factors left out are exactly 1: the product has the reference's bits.  (Boundary corners, lottery candidates.)
+__device__ __forceinline__ double de_pairs_point_wave_cut(int m, const double *xv, double *sf, int lane)
 {
-    const int m = P.d, RSW = de_rows_stride(m), n1m = P.n[1], n = lane & 15;
-    double *xv = scratch, *wv = xv + RSW;
-    for (int x = lane; x < m; x += 64) {
-        const int ix = ((x < p - 1) ? (int)rowA[x] : (x == p - 1) ? self : (int)rowB[x - p]) - 1;
-        xv[x] = par[ix]; wv[x] = par[n1m + ix];
-    }
-    if (lane < 56) xv[m + lane] = 1.0;                      // the evaluator's running products read up to 47 columns past a row's end
-    __builtin_amdgcn_wave_barrier();
-    if (P.arith) return de_fast_point_wave(P.ising_id, m, xv, wv, lane);      // TTX_ARITH=fast (ttx_fast.h)
-    if (P.de_cut) {
-        // exact, rows ended at the unit cut (nodes in [0,1]), 64 rows of the pair triangle per step: lane l walks row base+l left to
-        // right (its own running product, the reference's; one division per pair above the cut) and writes the factors, compacted
-        // by a wave prefix sum of the row lengths, to LDS; then the factors of the 64 rows go into `a` in order, sixteen LDS
-        // broadcasts ahead of sixteen dependent multiplies.  A row that is still above the cut after 32 pairs (nodes close to 1)
-        // sends the whole step down a plain serial walk.  The factors left out are exactly 1.
-        double *sf = wv + RSW;                               // 64 x 32 factors (the host sized the scratch for them)
         double a = 1.0;
         for (int base = 0; base < m; base += 64) {
             const int row = base + lane;
@@ -2307,17 +2293,33 @@ __device__ __forceinline__ double de_corner_wave(const DevProb &P, const double 
             for (int c = 0; c < 32; c++) if (c < L) sf[off + c] = fr[c];
             __builtin_amdgcn_wave_barrier();
             int t = 0;
-            for (; t + 16 <= total; t += 16) {
+            for (; t + 16 <= total; t += 16) {                              // two factors per ds_read_b128 (sf is 16-byte aligned)
                 double f16[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) f16[k] = sf[t + k];
+                for (int k = 0; k < 8; k++) { const Double2 q2 = *reinterpret_cast<const Double2 *>(sf + t + 2 * k); f16[2 * k] = q2.a; f16[2 * k + 1] = q2.b; }
 #pragma unroll
                 for (int k = 0; k < 16; k++) a = a * f16[k];
             }
             for (; t < total; t++) a = a * sf[t];
         }
-        return de_finish_vals(P.ising_id, a, m, xv, wv);
+        return a;
+}
+// corner entry of the Ising D / E integrands by the first wave of the block: multi-index = rowA (dims 1..p-1) | self | rowB.
+// Every pair by division with the row-wise evaluator of the lottery (ttx_de.h): the four DPP rows of the wave work on the same
+// element (lane n of a row = column n of a 16-column chunk of the pair triangle), the result is identical in all lanes.
+__device__ __forceinline__ double de_corner_wave(const DevProb &P, const double *par, const short *rowA, int p, int self, const short *rowB,
+                                                 double *scratch, int lane)
+{
+    const int m = P.d, RSW = de_rows_stride(m), n1m = P.n[1], n = lane & 15;
+    double *xv = scratch, *wv = xv + RSW;
+    for (int x = lane; x < m; x += 64) {
+        const int ix = ((x < p - 1) ? (int)rowA[x] : (x == p - 1) ? self : (int)rowB[x - p]) - 1;
+        xv[x] = par[ix]; wv[x] = par[n1m + ix];
     }
+    if (lane < 56) xv[m + lane] = 1.0;                      // the evaluator's running products read up to 47 columns past a row's end
+    __builtin_amdgcn_wave_barrier();
+    if (P.arith) return de_fast_point_wave(P.ising_id, m, xv, wv, lane);      // TTX_ARITH=fast (ttx_fast.h)
+    if (P.de_cut) return de_finish_vals(P.ising_id, de_pairs_point_wave_cut(m, xv, (double *)(((size_t)(wv + RSW) + 15) & ~(size_t)15), lane), m, xv, wv);   // (the host sized the scratch for the 64 x 32 factors)
     double a = 1.0;
     if (P.de_unit) for (int i = 0; i < m; i++) a = rows_span<true>(a, 1.0, xv + i, m - i, false, n);
     else for (int i = 0; i < m; i++) a = rows_span<false>(a, 1.0, xv + i, m - i, false, n);
