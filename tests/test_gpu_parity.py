@@ -620,19 +620,20 @@ def test_bad_bond_groups_are_refused(own):
         E.TTCross(s["n"], s["fun_id"], s["par"], 4, pivoting=2, accuracy=s["acc"], quad=s["quad"], nproc=len(own) - 1, mybonds=own)
 
 
-@pytest.mark.parametrize("env", [{}, {"TTX_DE_LANE": "1"}, {"TTX_DE_V2": "0"},
+@pytest.mark.parametrize("env", [{}, {"TTX_DE_LOT_POINT": "0"}, {"TTX_DE_LANE": "1"}, {"TTX_DE_V2": "0"},
                                  {"TTX_DE_CUT": "0"}, {"TTX_DE_CUT": "0", "TTX_DE_FASTDIV": "0"}, {"TTX_DE_CUT": "0", "TTX_LOTTERY_ROWS": "2"},
                                  {"TTX_DE_CUT": "0", "TTX_LOTTERY_WAVE": "0"}, {"TTX_DE_CUT": "0", "TTX_DE_V5": "1"}, {"TTX_DE_CUT": "0", "TTX_DE_V2": "0"},
                                  {"TTX_DE_CUT": "0", "TTX_DE_TEAM": "0"}, {"TTX_DE_CUT": "0", "TTX_DE_TEAM_UNITS": "1000000"},
                                  {"TTX_DE_CUT": "0", "TTX_DE_TEAM_UNITS": "1000000", "TTX_DE_FASTDIV": "0"},
                                  {"TTX_DE_CUT": "0", "TTX_DE_TEAM_UNITS": "0", "TTX_DE_TEAM6_UNITS": "1000000"}],
-                         ids=["compact_tables_default", "unit_cut_lane_per_element_no_tables", "compact_tables_generic_kernels",
+                         ids=["compact_tables_default", "lottery_from_compact_tables", "unit_cut_lane_per_element_no_tables", "compact_tables_generic_kernels",
                               "full_tables_round2_default", "general_division", "lottery_rows_with_tables", "lottery_lane_per_candidate", "relay_halfstep",
                               "lane_per_element", "wave_per_unit_halfstep", "team_halfstep_always", "team_halfstep_general_division",
                               "six_wave_team_halfstep_always"])
 def test_ising_de_kernel_variants_bit_exact(env, monkeypatch):
     """Every selectable variant of the D/E kernels gives the oracle's bits.  Round 3 (default for nodes in [0,1]): the compact tables whose
-    rows end at the unit cut (k_de_ctables, k_halfstep_dec, k_lottery_eval_dec, the wave-per-corner evaluator), the same cut with one
+    rows end at the unit cut (k_de_ctables, k_halfstep_dec, the row-parallel point evaluator of lottery candidates and boundary corners;
+    second case: the lottery candidates from the compact tables as at d > 160, k_lottery_eval_dec), the same cut with one
     lane per element and no tables, the compact tables through the generic lane-per-element kernels.  TTX_DE_CUT=0 -- the kernels
     of round 2 on the full pair triangle: the IEEE division instead of the short sequence for nodes in [0,1], the row-wise lottery
     with the pivots' factor tables (default: without), the lottery and the boundary corners with one lane per element, the
