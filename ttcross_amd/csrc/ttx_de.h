@@ -373,6 +373,9 @@ __device__ __forceinline__ void de_run_cut(double &a, double u, double x2, const
 // value of the fiber elements (left pivot pl | node i1 | node i2 | right pivot qr) of bond p, one per lane (pl, qr wave-uniform;
 // i1, i2 per lane), from the compact tables: tabulated factors by DPP row broadcasts, the bond-spanning tails by division, both
 // ended at the unit cut, everything in the reference's order.  All 64 lanes call it; dyn = the workgroup's dynamic LDS.
+#ifndef DEC_DEPTH
+#define DEC_DEPTH 2      // batches of 128 tabulated factors in flight per stream
+#endif
 __device__ __forceinline__ double dec_value(const DevProb &P, int g, int p, int first, int pl, int qr, int i1, int i2, double *dyn, int lane)
 {
     const int m = P.d, A = p - 1, B = m - p - 1;
@@ -393,7 +396,7 @@ __device__ __forceinline__ double dec_value(const DevProb &P, int g, int p, int 
     for (int x = lane; x < A; x += 64) cntL[x] = CLg[x];
     const int totL = UNI(CLg[m]), totR = UNI(CRg[m]);
     const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
-    WStreamD<2> sl, sr;                                                // tabulated factors by DPP row broadcasts
+    WStreamD<DEC_DEPTH> sl, sr;                                                // tabulated factors by DPP row broadcasts
     sl.init(TLg, totL, ringL, lane);
     sr.init(TRg, totR, ringR, lane);
     __syncthreads();
