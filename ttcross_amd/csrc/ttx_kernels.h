@@ -839,10 +839,13 @@ __global__ __launch_bounds__(256) void k_init_samples(DevProb P, int snum, int n
         // whole pair triangle (7 ms of the 220 ms of D_256 went into this kernel)
         const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, n1m = P.n[1];
         double *xv = (double *)rows + (size_t)wv * 2 * (m + 64), *wvv = xv + (m + 64);
+        int *nl = (int *)((double *)rows + (size_t)nw * 2 * (m + 64));      // mode sizes (one global round trip instead of one per sample)
+        for (int x = tid; x < m; x += blockDim.x) nl[x] = P.n[x + 1];
+        __syncthreads();
         for (int il = wv; il < nn * snum; il += nw) {
             const int k = il % nn + 1, sft = il / nn;
             __builtin_amdgcn_wave_barrier();
-            for (int x = lane; x < m; x += 64) { const int ix = (k - 1 + sft * x) % P.n[x + 1]; xv[x] = par[ix]; wvv[x] = par[n1m + ix]; }
+            for (int x = lane; x < m; x += 64) { const int ix = (k - 1 + sft * x) % nl[x]; xv[x] = par[ix]; wvv[x] = par[n1m + ix]; }
             __builtin_amdgcn_wave_barrier();
             const double f = de_fast_point_wave(P.ising_id, m, xv, wvv, lane);
             const double a = fabs(f);
