@@ -192,6 +192,45 @@ struct WStreamD {
     }
 };
 
+// The same stream consumed by LDS BROADCASTS instead of DPP row broadcasts: every lane reads the ring buffer itself, two factors per
+// ds_read_b128, one v_mul_f64 per factor.  A DPP broadcast of a double is two VALU instructions on top of the multiply; where a
+// kernel keeps several such chains per SIMD busy (the lottery: one wave per candidate, 2.6 waves per SIMD) the VALU issue is the
+// bound and the LDS port is idle -- the half-steps with at most one wave per SIMD stay with WStreamD.  Same factors, same order.
+struct WStreamL {
+    const double *g; double *buf; double r[2][2]; int total, nextb, rd;
+    __device__ __forceinline__ void ld(int b, int lane, double &x, double &y) const
+    { const int ix = b * 128 + 2 * lane; x = ix < total ? g[ix] : 1.0; y = ix + 1 < total ? g[ix + 1] : 1.0; }
+    __device__ __forceinline__ void init(const double *g_, int total_, double *buf_, int lane)
+    { g = g_; total = total_; buf = buf_; nextb = 2; rd = 128; ld(0, lane, r[0][0], r[0][1]); ld(1, lane, r[1][0], r[1][1]); }
+    __device__ __forceinline__ void refill(int lane)
+    {
+        __builtin_amdgcn_wave_barrier();
+        buf[2 * lane] = r[0][0]; buf[2 * lane + 1] = r[0][1];
+        r[0][0] = r[1][0]; r[0][1] = r[1][1];
+        ld(nextb, lane, r[1][0], r[1][1]); nextb++; rd = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ double chain(double a, int cnt, int lane)
+    {
+        while (cnt > 0) {
+            if (rd == 128) refill(lane);
+            int c = cnt < 128 - rd ? cnt : 128 - rd;
+            cnt -= c;
+            if ((rd & 1) && c > 0) { a = a * buf[rd]; rd++; c--; }                 // up to a 16-byte boundary
+            for (; c >= 8; c -= 8, rd += 8) {
+                double f[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const Double2 q2 = *reinterpret_cast<const Double2 *>(buf + rd + 2 * k); f[2 * k] = q2.a; f[2 * k + 1] = q2.b; }
+#pragma unroll
+                for (int k = 0; k < 8; k++) a = a * f[k];
+            }
+            for (; c > 0; c--, rd++) a = a * buf[rd];
+        }
+        return a;
+    }
+    __device__ __forceinline__ double chain_from_boundary(double a, int cnt, int lane) { return chain(a, cnt, lane); }
+};
+
 #ifndef DE_RUNW
 #define DE_RUNW 8        // division chains interleaved per batch (16 measured 1 % faster on D_256: not worth the registers)
 #endif
@@ -376,6 +415,7 @@ __device__ __forceinline__ void de_run_cut(double &a, double u, double x2, const
 #ifndef DEC_DEPTH
 #define DEC_DEPTH 2      // batches of 128 tabulated factors in flight per stream
 #endif
+template <class STREAM>
 __device__ __forceinline__ double dec_value(const DevProb &P, int g, int p, int first, int pl, int qr, int i1, int i2, double *dyn, int lane)
 {
     const int m = P.d, A = p - 1, B = m - p - 1;
@@ -396,7 +436,7 @@ __device__ __forceinline__ double dec_value(const DevProb &P, int g, int p, int 
     for (int x = lane; x < A; x += 64) cntL[x] = CLg[x];
     const int totL = UNI(CLg[m]), totR = UNI(CRg[m]);
     const double x1 = nodes[i1], x2 = nodes[i2], w1 = weights[i1], w2 = weights[i2];
-    WStreamD<DEC_DEPTH> sl, sr;                                                // tabulated factors by DPP row broadcasts
+    STREAM sl, sr;                                                // tabulated factors by DPP row broadcasts
     sl.init(TLg, totL, ringL, lane);
     sr.init(TRg, totR, ringR, lane);
     __syncthreads();
@@ -447,7 +487,7 @@ __global__ __launch_bounds__(64) void k_lottery_eval_dec(DevProb P)
     if (il >= nlot) return;
     const int *c_ = P.lotc + ((size_t)g * P.lot_max + il) * 4;
     const int i = UNI(c_[0]), j = UNI(c_[1]), k = UNI(c_[2]), q = UNI(c_[3]);
-    const double f = dec_value(P, g, UNI(st.p), UNI(gs.first), i - 1, q - 1, j - 1, k - 1, dyn, lane);
+    const double f = dec_value<WStreamL>(P, g, UNI(st.p), UNI(gs.first), i - 1, q - 1, j - 1, k - 1, dyn, lane);
     if (lane == 0) P.lotf[(size_t)g * P.lot_max + il] = f;
 }
 
@@ -522,7 +562,7 @@ __global__ __launch_bounds__(64) void k_halfstep_dec(DevProb P, int h, int dir, 
     const bool live = vmode < nm;
     const int pl = iscol ? pv : c_ii - 1, qr = iscol ? c_qq - 1 : pv;         // left / right pivot of this wave
     const int i1 = iscol ? (live ? vmode : 0) : c_jj - 1, i2 = iscol ? c_kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
-    double a = dec_value(P, g, p, first, pl, qr, i1, i2, dyn, lane);
+    double a = dec_value<WStreamD<DEC_DEPTH>>(P, g, p, first, pl, qr, i1, i2, dyn, lane);
     // ---- fiber store, amax, residual, arg-max: as k_halfstep, on the fiber's linear index t ----
     const int u_ = iscol ? pv : vmode, v_ = iscol ? vmode : pv;        // col: (i, j) ; row: (k, q), 0-based
     const int t = iscol ? (u_ + r0 * v_) : (u_ + n2 * v_);
