@@ -412,6 +412,9 @@ __device__ __forceinline__ void de_run_cut(double &a, double u, double x2, const
 // value of the fiber elements (left pivot pl | node i1 | node i2 | right pivot qr) of bond p, one per lane (pl, qr wave-uniform;
 // i1, i2 per lane), from the compact tables: tabulated factors by DPP row broadcasts, the bond-spanning tails by division, both
 // ended at the unit cut, everything in the reference's order.  All 64 lanes call it; dyn = the workgroup's dynamic LDS.
+#ifndef DEC_HALF_STREAM
+#define DEC_HALF_STREAM WStreamD<DEC_DEPTH>     // stream of the half-step's tabulated factors (WStreamL: LDS broadcasts)
+#endif
 #ifndef DEC_DEPTH
 #define DEC_DEPTH 2      // batches of 128 tabulated factors in flight per stream
 #endif
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(64) void k_halfstep_dec(DevProb P, int h, int dir, 
     const bool live = vmode < nm;
     const int pl = iscol ? pv : c_ii - 1, qr = iscol ? c_qq - 1 : pv;         // left / right pivot of this wave
     const int i1 = iscol ? (live ? vmode : 0) : c_jj - 1, i2 = iscol ? c_kk - 1 : (live ? vmode : 0);   // node index of dim p / p+1
-    double a = dec_value<WStreamD<DEC_DEPTH>>(P, g, p, first, pl, qr, i1, i2, dyn, lane);
+    double a = dec_value<DEC_HALF_STREAM>(P, g, p, first, pl, qr, i1, i2, dyn, lane);
     // ---- fiber store, amax, residual, arg-max: as k_halfstep, on the fiber's linear index t ----
     const int u_ = iscol ? pv : vmode, v_ = iscol ? vmode : pv;        // col: (i, j) ; row: (k, q), 0-based
     const int t = iscol ? (u_ + r0 * v_) : (u_ + n2 * v_);
