@@ -144,6 +144,7 @@ struct ttx_engine {
     int de_test_fault = 0;              // test hook (TTX_DE_TEST_FAULT=<sweep>): the team half-steps of that sweep get a grid of one unit
     int de_team6_units = 1024; size_t lds_det6 = 0;                                      // ... and by teams of 6 waves, several per CU, for the launches above that   // ... by a team of 14 waves per unit (k_halfstep_det) while the ranks are small
     int lot_rows = 0; size_t lds_der = 0;   // ... four candidates per wave, one per DPP row (k_lottery_eval_de_rows)
+    double *h_svd = nullptr; double svd_seq = 0.0;   // pinned: [seq, rank, sweeps, sv...] of the core dtt_svd works on (k_svd_report)
     int de_lot_point = 0;                   // Ising D/E, unit-cut path: lottery candidates row-parallel without tables (k_lottery_eval_decp)
     int lot_wave = 0;                       // Ising D/E: lottery candidates and boundary corners by the row-wise wave evaluator (ttx_de.h)
     int mvn_v2 = 0; size_t lds_mvn = 0;     // mvn: wave-per-pivot half-step and wave-per-candidate lottery (ttx_mvn.h)
@@ -708,6 +709,7 @@ extern "C" void ttx_destroy(ttx_engine *h)
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->h_sum_base) (void)hipHostFree(h->h_sum_base);
     if (h->h_val) (void)hipHostFree(h->h_val);
+    if (h->h_svd) (void)hipHostFree(h->h_svd);
     if (h->qstream) (void)hipStreamDestroy(h->qstream);
     for (int x = 0; x < 2; x++) { if (h->ev_sum[x]) (void)hipEventDestroy(h->ev_sum[x]); if (h->ev_val[x]) (void)hipEventDestroy(h->ev_val[x]); }
     if (h->h_msg) (void)hipHostFree(h->h_msg);
@@ -2350,6 +2352,32 @@ static int ort_impl(ttx_engine *h)
     return TTX_OK;
 }
 
+// rank, Jacobi sweeps and singular values of the core just decomposed: written by the device into pinned memory, polled here
+static int svd_fetch(ttx_engine *h, const double *sv, const int *info, int q, int *inf2, double *svh)
+{
+    if (!h->h_svd) HIPCHECK(hipHostMalloc((void **)&h->h_svd, sizeof(double) * ((size_t)h->RM + 8)));
+    if (getenv("TTX_SVD_POLL") && atoi(getenv("TTX_SVD_POLL")) == 0) {
+        HIPCHECK(hipMemcpyAsync(inf2, info, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipMemcpyAsync(svh, sv, sizeof(double) * q, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        return TTX_OK;
+    }
+    h->svd_seq += 1.0;
+    hipLaunchKernelGGL(k_svd_report, dim3(1), dim3(64), 0, h->stream, sv, info, q, (volatile double *)h->h_svd, h->svd_seq);
+    volatile double *hv = h->h_svd;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (hv[0] != h->svd_seq) {
+        if ((++spins & 0xfff) == 0) {
+            if (hipStreamQuery(h->stream) == hipSuccess && hv[0] != h->svd_seq) { HIPCHECK(hipStreamSynchronize(h->stream)); break; }   // (kernel failed to launch: do not spin for ever)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) return fail(TTX_EHIP, "dtt_svd: no report from the device within 30 s");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    inf2[0] = (int)hv[1]; inf2[1] = (int)hv[2];
+    for (int j = 0; j < q; j++) svh[j] = hv[3 + j];
+    return TTX_OK;
+}
 static int svd_impl(ttx_engine *h, double tol, int rmax)
 {
     const int d = h->d, RM = h->RM; const size_t SS = h->P.SS;
@@ -2371,9 +2399,7 @@ static int svd_impl(ttx_engine *h, double tol, int rmax)
             if ((rc = qr(h, mm, nn, h->Wa, Rm, tau))) return rc;        // Wa -> Q (mm x nn), Rm = R (nn x nn)
             if ((rc = jacobi(h, nn, nn, Rm, Vb, sv, perm, info, tol, rmax))) return rc;
             int inf2[2];
-            HIPCHECK(hipMemcpyAsync(inf2, info, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
-            HIPCHECK(hipMemcpyAsync(svh.data(), sv, sizeof(double) * nn, hipMemcpyDeviceToHost, h->stream));
-            HIPCHECK(hipStreamSynchronize(h->stream));
+            if ((rc = svd_fetch(h, sv, info, nn, inf2, svh.data()))) return rc;
             const int rr = inf2[0];
             s2 = 0.0; for (int j = 0; j < rr; j++) s2 += svh[j] * svh[j];
             const double nrm = std::sqrt(s2);
@@ -2394,9 +2420,7 @@ static int svd_impl(ttx_engine *h, double tol, int rmax)
         hipLaunchKernelGGL(k_transpose, g1((size_t)mm * mm), dim3(256), 0, h->stream, mm, mm, Rm, Rt);
         if ((rc = jacobi(h, mm, mm, Rt, Vb, sv, perm, info, tol, rmax))) return rc;
         int inf[2];
-        HIPCHECK(hipMemcpyAsync(inf, info, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipMemcpyAsync(svh.data(), sv, sizeof(double) * mm, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
+        if ((rc = svd_fetch(h, sv, info, mm, inf, svh.data()))) return rc;
         const int rr = inf[0];
         if (getenv("TTX_JAC_TRACE")) fprintf(stderr, "svd core %d: %d x %d, %d Jacobi sweeps, rank %d\n", k, mm, mm, inf[1], rr);
         s2 = 0.0; for (int j = 0; j < rr; j++) s2 += svh[j] * svh[j];

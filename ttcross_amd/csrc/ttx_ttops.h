@@ -641,6 +641,15 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(int p, int q, double *Xg, d
     }
 }
 
+// rank and singular values of one core straight into pinned host memory (dtt_svd needs them to shape the next launches): the host
+// polls host[0] for `seq` instead of two device-to-host copies and a stream synchronisation (30-40 us per core)
+__global__ void k_svd_report(const double *sv, const int *info, int q, volatile double *host, double seq)
+{
+    for (int j = threadIdx.x; j < q; j += blockDim.x) host[3 + j] = sv[j];
+    if (threadIdx.x == 0) { host[1] = (double)info[0]; host[2] = (double)info[1]; }
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); host[0] = seq; }
+}
 // out (rows x rr) <- in(:, perm[0..rr)) * diag(scale[c])   (scale == nullptr: 1)
 __global__ void k_take_cols(int rows, int rr, const double *in, int ldin, const int *perm, const double *scale, double sdiv, double *out)
 {
