@@ -41,9 +41,10 @@ def one_job():
     import oracle_lib as O
     from ttcross_amd import drivers as D
     from ttcross_amd import engine as E
-    s = D.ising_setup(kind, m, n)
-    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"],
-                   nproc=ng, device=dev, world_rank=rank, world_size=world)
+    fast = os.environ.get("TTX_MP_FAST") == "1"       # TTX_ARITH=fast: the checker is the single-process engine in the same mode (same groups)
+    s = D.box_setup("mvn", m, n) if kind == "mvn" else D.ising_setup(kind, m, n)
+    tt = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s.get("aux"),
+                   nproc=ng, device=dev, world_rank=rank, world_size=world, arith="fast" if fast else "exact")
     if transport == "rccl":
         tt.comm_init(dist)
     elif transport == "shm":
@@ -52,7 +53,14 @@ def one_job():
         tt.set_dist_transport(dist)
     tt.run()
     val = tt.quad(s["quad"])
-    oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng)
+    if fast:
+        one = E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], aux=s.get("aux"), nproc=ng, device=dev,
+                        arith="fast").run()
+        oo = dict(tapes=one.tapes(), sweeps=one.sweeps(), neval=one.neval, r=one.ranks(), value=one.quad(s["quad"]),
+                  cores=[one.core(k) for k in range(1, one.d + 1)])
+        one.close()
+    else:
+        oo = O.dmrgg(s["n"], s["fun_id"], s["par"], r, piv=piv, accuracy=s["acc"], quad=s["quad"], tru=s["tru"], nproc=ng, aux=s.get("aux"))
     bad = []
     if not np.array_equal(tt.tapes()[:, 1:tt.d], oo["tapes"][:, 1:tt.d]):
         bad.append("tapes")

@@ -379,6 +379,18 @@ def test_multi_process_post_processing(world, args):
         assert rc == 0 and " OK" in o, o[-3000:] + e[-3000:]
 
 
+@pytest.mark.parametrize("world,args", [(3, "d 8 33 10 2 3"), (2, "mvn 6 17 8 2 4"), (2, "e 20 9 6 3 2")])
+def test_multi_process_fast_mode_equals_single_process_fast_mode(world, args):
+    """TTX_ARITH=fast on a multi-process job (persistent per-bond tables of Ising D/E and mvn, boundary pivots' entries built from
+    the RECEIVED messages): every record and every core identical to the single-process engine in the same mode and groups."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = _spawn_ranks(world, [sys.executable, os.path.join(root, "tests", "mp_worker.py")] + args.split() + ["shm"], {"TTX_MP_FAST": "1"})
+    for rc, o, e in outs:
+        assert rc == 0 and " OK" in o, o[-2000:] + e[-2000:]
+
+
 def test_shm_transport_survives_stale_and_reused_segment_names():
     """The attach handshake of ttx_comm_init_shm (a nonce per initialisation): (1) a job whose processes die without closing
     leaves its segment behind under the name -- ready = 1, handshake over --; the next job under the SAME name must not join
