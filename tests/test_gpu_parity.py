@@ -514,9 +514,11 @@ def _full(cores):
     return t.reshape(t.shape[1:-1])
 
 
-@pytest.mark.parametrize("m,n,r,piv,ng", [(6, 33, 12, 2, 1), (10, 25, 16, 2, 1), (7, 9, 8, 2, 3), (9, 51, 32, 2, 1)],
-                         ids=["c6", "c10", "c7_3groups", "c9_r32_tsqr"])     # the last: 1632 x 32 unfoldings, tall-skinny QR over several workgroups
-def test_tt_ort_svd_norm_dot(m, n, r, piv, ng):
+@pytest.mark.parametrize("m,n,r,piv,ng,env", [(6, 33, 12, 2, 1, {}), (10, 25, 16, 2, 1, {}), (7, 9, 8, 2, 3, {}), (9, 51, 32, 2, 1, {}),
+                                              (9, 51, 32, 2, 1, {"TTX_QR_OWN": "0", "TTX_SVD_POLL": "0"}), (9, 51, 32, 2, 1, {"TTX_QR_PANEL": "64", "TTX_QR_THREADS": "512"})],
+                         ids=["c6", "c10", "c7_3groups", "c9_r32_tsqr", "c9_r32_lds_qr_and_copied_rank", "c9_r32_short_panels_8_waves"])
+# c9: 1632 x 32 unfoldings, tall-skinny QR over several workgroups; default = register-resident QR (k_qr_own) and the polled rank report
+def test_tt_ort_svd_norm_dot(m, n, r, piv, ng, env, monkeypatch):
     """N1 (A12/A13): dtt_ort / dtt_svd / dtt_norm / dtt_dot / dtt_ijk on the device against the oracle's restatement
     and the GENUINE reference's numbers (tests/golden/ttops_*.txt).  Floating point: LAPACK's QR/SVD are restated
     (Householder with a different reduction order, Jacobi SVD, fp64 MFMA GEMMs): tolerance 1e-11 relative to the
@@ -524,6 +526,8 @@ def test_tt_ort_svd_norm_dot(m, n, r, piv, ng):
     import os
     from golden_util import GOLDEN
     from test_oracle_ttops import _fixture, probe_indices
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
     s = D.ising_setup("c", m, n)
     mk = lambda: E.TTCross(s["n"], s["fun_id"], s["par"], r, pivoting=piv, accuracy=s["acc"], nproc=ng).run()
     tt = mk()
