@@ -797,7 +797,9 @@ def test_stream_file_read_write_against_reference_file(tmp_path):
                                       (3, [33] * 5, [1, 16, 24, 24, 16, 1]), (4, [2, 3], [1, 2, 1]),
                                       (5, [2, 2, 3, 2], [1, 5, 7, 4, 1]), (6, [3, 2, 2, 2, 4], [1, 9, 14, 11, 6, 1]),
                                       # 6464 x 64 unfoldings (the cores of D_256): four levels of the tall-skinny QR, 64 x 64 Jacobi SVD
-                                      (7, [101] * 4, [1, 64, 64, 64, 1])])
+                                      (7, [101] * 4, [1, 64, 64, 64, 1]),
+                                      # 144 x 100 and 1200 x 12 unfoldings: eight columns per wave of the register-resident QR, a wide middle core
+                                      (8, [12] * 4, [1, 12, 100, 12, 1])])
 def test_uploaded_train_roundtrip_and_tt_lib(tmp_path, seed, n, r):
     """ttx_from_tt: arbitrary (random) trains, not only sweep results, through ort / svd / norm / dot / quad against the
     oracle's tt_lib restatement (tolerances as in test_tt_ort_svd_norm_dot), plus file round trip (bit-exact)."""
