@@ -6,6 +6,7 @@ KSEL=fuzz_random run "fuzz 2500 cases seed 207 (default: compact D/E tables, clu
 KSEL=fuzz_random run "fuzz 1200 cases seed 209, D/E lane per element with the unit cut" TTX_DE_LANE=1 TTX_FUZZ_CASES=1200 TTX_FUZZ_SEED=209
 KSEL=fuzz_random run "fuzz 1200 cases seed 211, compact tables through the generic kernels" TTX_DE_V2=0 TTX_FUZZ_CASES=1200 TTX_FUZZ_SEED=211
 KSEL=fuzz_random run "fuzz 800 cases seed 213, round-2 kernels (TTX_DE_CUT=0)" TTX_DE_CUT=0 TTX_FUZZ_CASES=800 TTX_FUZZ_SEED=213
+KSEL=fuzz_random run "fuzz 800 cases seed 215, lottery candidates from the compact tables" TTX_DE_LOT_POINT=0 TTX_FUZZ_CASES=800 TTX_FUZZ_SEED=215
 KSEL=soak run "soak 600 runs per configuration" TTX_SOAK_RUNS=600
 KSEL=multi_process run "multi-process fuzz 16 jobs seed 227" TTX_MPFUZZ_CASES=16 TTX_FUZZ_SEED=227
 KSEL=tt_lib run "tt_lib fuzz 40 trains seed 229 (k_qr_own)" TTX_TTOPSFUZZ_CASES=40 TTX_FUZZ_SEED=229
