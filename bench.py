@@ -29,9 +29,9 @@ WORKLOADS = {
     "c64": (("ising", "c", 64, 51, 32, 2), "Ising C_64 n=51 r=32 piv=2 (d=63)"),
     "c16": (("ising", "c", 16, 51, 32, 2), "Ising C_16 n=51 r=32 piv=2 (d=15)"),
     "d32": (("ising", "d", 32, 51, 24, 2), "Ising D_32 n=51 r=24 piv=2 (d=31)"),
-    # BASELINE config 5 at full size: about 12 s per step on one MI355X (use --steps 1 --warmup 0 --no-cpu-baseline)
+    # BASELINE config 5 at full size: 0.53 s per step exact (3.7 s with TTX_DE_CUT=0), 0.21 s with --arith fast on one MI355X
     "d256": (("ising", "d", 256, 101, 64, 5), "Ising D_256 n=101 r=64 piv=5 (d=255)"),
-    # BASELINE config 4 at full size (4 bond groups by default): about 3 s per step
+    # BASELINE config 4 at full size (4 bond groups by default): 1.2 s per step exact, 0.15 s with --arith fast
     "mvn128": (("mvn", "mvn", 128, 33, 50, 2), "mvn d=128 n=33 r=50 piv=2 (multivariate-normal density, test_crs_mvn)"),
 }
 # tt_lib utilities on the RESULT train of a sweep: `ort` = dtt_ort (left-to-right Householder QR), `svd` = dtt_svd
