@@ -405,8 +405,11 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
             else { ttx_destroy(h); return fail(TTX_EINVAL, "TTX_ARITH must be exact or fast (got %s)", e); }
         }
         h->want_fast = want && !nofun;
+        // the integrand reads node par[ind - 1] for ind up to the LARGEST mode size (lib: nodes + ind), whatever n(1) is
+        int nnode = 0; for (int k = 0; k < d; k++) nnode = std::max(nnode, (int)cfg->n[k]);
+        nnode = std::min(nnode, (int)cfg->npar);
         bool unit = true;               // Ising: all nodes in [0,1] (every running product non-increasing: the cut at 2^-54 is valid)
-        if (cfg->fun_id == TTX_FUN_ISING) for (int j = 0; j < cfg->n[0]; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) unit = false;
+        if (cfg->fun_id == TTX_FUN_ISING) for (int j = 0; j < nnode; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) unit = false;
         P.arith = (want && !nofun && ((cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && unit) || cfg->fun_id == TTX_FUN_MVN)) ? 1 : 0;
         if (P.arith) {
             P.FD = d + 1;
@@ -435,14 +438,14 @@ static int create_impl(ttx_engine **out, const ttx_config *cfg, bool nofun)
     if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && !P.arith && de_lane) {
         // one fiber element per lane, every pair by division, rows ended at the unit cut (f_ising_de with `unit`): no tables, no teams
         P.de_unit = 1;
-        for (int j = 0; j < cfg->n[0]; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) P.de_unit = 0;
+        for (int j = 0; j < std::min((int)cfg->npar, std::max((int)cfg->n[0], (int)NM)); j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) P.de_unit = 0;
     }
     if (cfg->fun_id == TTX_FUN_ISING && P.ising_id != 1 && !P.arith && !de_lane && !(getenv("TTX_DE_TABLES") && atoi(getenv("TTX_DE_TABLES")) == 0)) {
         P.de_npair = d * (d + 1) / 2;
         A_(dev_alloc(h, &P.deTL, G * (size_t)P.de_npair * RM)); A_(dev_alloc(h, &P.deTR, G * (size_t)P.de_npair * RM));
         A_(dev_alloc(h, &P.deUL, G * (size_t)(d + 1) * RM));
         P.de_unit = 1;                  // nodes in [0,1]: every running product stays in [0,1] and fdiv_unit is exact
-        for (int j = 0; j < cfg->n[0]; j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) P.de_unit = 0;
+        for (int j = 0; j < std::min((int)cfg->npar, std::max((int)cfg->n[0], (int)NM)); j++) if (!(cfg->par[j] >= 0.0 && cfg->par[j] <= 1.0)) P.de_unit = 0;
         if (getenv("TTX_DE_FASTDIV") && atoi(getenv("TTX_DE_FASTDIV")) == 0) P.de_unit = 0;
         // nodes in [0,1]: compact tables, every row of the pair triangle ends at the unit cut (k_de_ctables, k_halfstep_dec; same bits).
         // TTX_DE_CUT=0: the full tables and the kernels of round 2 (wave teams, row-wise lottery)
